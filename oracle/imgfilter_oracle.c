@@ -1,0 +1,411 @@
+/*
+ * imgfilter_oracle.c — CPU restatement of the reference's CPU comparison paths.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker / the timed CPU baseline.  The product path
+ * (libmi355_imgfilter.so) never links, loads or falls back to it.
+ *
+ * Parity status (see DESIGN.md "Oracle"):
+ *   - oracle_gauss_weights : PINNED against the reference's own
+ *     Controller::_GenerateGausianKernel compiled from /root/reference
+ *     (oracle/_ref, tests/test_oracle_ref.py) and by committed vectors that
+ *     build produced (tests/golden/gauss_weights_ref.json).
+ *   - oracle_gray_*, oracle_gauss_rgba, oracle_sobel_* : PARITY UNPINNED.  The
+ *     reference keeps those loops inside translation units that include
+ *     <opencv2/opencv.hpp> (absent here, not installable) and ships no tests,
+ *     golden outputs or fixtures for them.  They are restated line by line from
+ *     the cited source and pinned only by hand-derivable known answers.
+ *   - Sobel additionally restates OpenCV's *documented* filter2D / magnitude /
+ *     convertTo semantics (OpenCV is an un-vendored, un-pinned apt dependency of
+ *     the reference: libopencv-dev, .github/workflows/ci.yml:33).
+ *
+ * Build: plain C, -O2 -ffp-contract=off, no -march flags (the reference is a
+ * default x86-64 build: no FMA contraction can occur there).
+ *
+ * All citations are relative to /root/reference/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#if defined(__GNUC__)
+#define ORACLE_API __attribute__((visibility("default")))
+#else
+#define ORACLE_API
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Grayscale — src/Grayscale/grayscale.cpp:233-237                            */
+/*             (= src/RealtimeImageProcessing/src/Comparator.cpp:37-41)       */
+/*   int b,g,r;  uchar gray = static_cast<uchar>(0.299*r + 0.587*g + 0.114*b) */
+/* double arithmetic, left-to-right, C truncation.                            */
+/* ------------------------------------------------------------------------- */
+static inline uint8_t gray_of(int r, int g, int b)
+{
+    double v = 0.299 * r + 0.587 * g + 0.114 * b;
+    return (uint8_t)v;
+}
+
+ORACLE_API uint8_t oracle_gray_px(int r, int g, int b) { return gray_of(r, g, b); }
+
+/* Exactly the reference layout: 3-channel BGR rows in, 1-channel rows out
+ * (grayscale.cpp:226-242).  Strides are tightly packed. */
+ORACLE_API void oracle_gray_bgr(const uint8_t *bgr, uint8_t *out, int w, int h)
+{
+    for (int row = 0; row < h; row++) {
+        const uint8_t *in_row = bgr + (size_t)row * w * 3;
+        uint8_t *out_row = out + (size_t)row * w;
+        for (int col = 0; col < w; col++) {
+            int b = in_row[col * 3];
+            int g = in_row[col * 3 + 1];
+            int r = in_row[col * 3 + 2];
+            out_row[col] = gray_of(r, g, b);
+        }
+    }
+}
+
+/* Same arithmetic on the hot path's pixel layout (interleaved RGBA, produced by
+ * cv::cvtColor(BGR2RGBA): src/RealtimeImageProcessing/src/ProgramHandler.cpp:127).
+ * One byte per pixel out — the CPU path's output shape. */
+ORACLE_API void oracle_gray_rgba_1ch(const uint8_t *rgba, uint8_t *out, int w, int h)
+{
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++)
+        out[i] = gray_of(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]);
+}
+
+/* API output shape of Controller::PerformCLImageGrayscaling in buffer mode
+ * (src/RealtimeImageProcessing/src/Controller.cpp:442,510 with
+ * kernel/grayscale_base.cl:17): w*h*4 bytes, (g,g,g,255) per pixel.  The gray
+ * value itself follows the CPU formula above (the parity target). */
+ORACLE_API void oracle_gray_rgba(const uint8_t *rgba, uint8_t *out_rgba, int w, int h)
+{
+    size_t n = (size_t)w * h;
+    for (size_t i = 0; i < n; i++) {
+        uint8_t g = gray_of(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2]);
+        out_rgba[4 * i] = g;
+        out_rgba[4 * i + 1] = g;
+        out_rgba[4 * i + 2] = g;
+        out_rgba[4 * i + 3] = 255;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Gaussian weights — src/GaussianBlur/src/Controller.cpp:342-362             */
+/*   (= src/RealtimeImageProcessing/src/Controller.cpp:352-372)               */
+/*   float value = exp(-(x*x + y*y) / (2*sigma*sigma)) / (2*M_PI*sigma*sigma);*/
+/* Promotion chain: int numerator / float denominator -> float argument;      */
+/* unqualified exp() on a float argument; result divided by a double          */
+/* (2*M_PI is double); stored to float; float running sum; value /= sum.      */
+/* Which exp overload the reference's build picks was decided by the real      */
+/* compile in oracle/_ref (tests/test_oracle_ref.py compares bit patterns):    */
+/* it is ::exp(double).                                                        */
+/* ------------------------------------------------------------------------- */
+ORACLE_API int oracle_gauss_weights(int k, float sigma, float *out)
+{
+    /* the reference loops y,x over [-half, half] and indexes (y+half)*k+(x+half):
+     * for even k that walks one past each row; only odd k is well defined and
+     * only odd k is accepted here. */
+    if (k <= 0 || !out || (k & 1) == 0)
+        return -1;
+    int half = k / 2;
+    float sum = 0.0f;
+    for (int y = -half; y <= half; y++) {
+        for (int x = -half; x <= half; x++) {
+            float arg = -(x * x + y * y) / (2 * sigma * sigma);
+            /* The reference's unqualified exp() binds to ::exp(double) (only
+             * <cmath> is included, so no float overload is visible in the global
+             * namespace): the float argument is widened, exp is evaluated in
+             * double.  PINNED: bit-identical to the reference build (oracle/_ref)
+             * on every (k, sigma) tried; the expf variant below is not. */
+            float value = (float)(exp((double)arg) / (2 * M_PI * sigma * sigma));
+            out[(y + half) * k + (x + half)] = value;
+            sum += value;
+        }
+    }
+    for (int i = 0; i < k * k; i++)
+        out[i] /= sum;
+    return 0;
+}
+
+/* Deliberately WRONG variant (exp evaluated in float), kept so the pinning test
+ * can show that the comparison against the reference build discriminates: this
+ * one differs from the reference in most (k, sigma) cases. */
+ORACLE_API int oracle_gauss_weights_fexp(int k, float sigma, float *out)
+{
+    if (k <= 0 || !out || (k & 1) == 0)
+        return -1;
+    int half = k / 2;
+    float sum = 0.0f;
+    for (int y = -half; y <= half; y++) {
+        for (int x = -half; x <= half; x++) {
+            float arg = -(x * x + y * y) / (2 * sigma * sigma);
+            float value = (float)(expf(arg) / (2 * M_PI * sigma * sigma));
+            out[(y + half) * k + (x + half)] = value;
+            sum += value;
+        }
+    }
+    for (int i = 0; i < k * k; i++)
+        out[i] /= sum;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Gaussian blur — src/GaussianBlur/GaussianBlur.cpp:234-261                  */
+/* y,x outer; ky outer / kx inner; taps clamped to the image; four float      */
+/* accumulators; sum += pixel[c] * weight (u8 -> int -> float multiply, then  */
+/* a separate add); no division by the accumulated weight; store              */
+/* uchar(clamp(sum, 0, 255)) (truncation).  All four channels incl. alpha.    */
+/* ------------------------------------------------------------------------- */
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static void gauss_rows(const uint8_t *in, uint8_t *out, int w, int h, int k, const float *wt,
+                       int y0, int y1)
+{
+    int half = k / 2;
+    for (int y = y0; y < y1; y++) {
+        for (int x = 0; x < w; x++) {
+            float sumR = 0.0f, sumG = 0.0f, sumB = 0.0f, sumA = 0.0f;
+            for (int ky = -half; ky <= half; ky++) {
+                for (int kx = -half; kx <= half; kx++) {
+                    int nx = clampi(x + kx, 0, w - 1);
+                    int ny = clampi(y + ky, 0, h - 1);
+                    const uint8_t *p = in + ((size_t)ny * w + nx) * 4;
+                    float weight = wt[(ky + half) * k + (kx + half)];
+                    sumR += p[0] * weight;
+                    sumG += p[1] * weight;
+                    sumB += p[2] * weight;
+                    sumA += p[3] * weight;
+                }
+            }
+            uint8_t *o = out + ((size_t)y * w + x) * 4;
+            o[0] = (uint8_t)clampf(sumR, 0.0f, 255.0f);
+            o[1] = (uint8_t)clampf(sumG, 0.0f, 255.0f);
+            o[2] = (uint8_t)clampf(sumB, 0.0f, 255.0f);
+            o[3] = (uint8_t)clampf(sumA, 0.0f, 255.0f);
+        }
+    }
+}
+
+ORACLE_API int oracle_gauss_rgba(const uint8_t *in, uint8_t *out, int w, int h, int k,
+                                 const float *weights)
+{
+    if (w <= 0 || h <= 0 || k <= 0 || (k & 1) == 0)
+        return -1;
+    gauss_rows(in, out, w, h, k, weights, 0, h);
+    return 0;
+}
+
+/* Same loops, rows split over OpenMP threads (the reference itself has no
+ * threading; this variant exists only for the "all host cores" baseline). */
+ORACLE_API int oracle_gauss_rgba_mt(const uint8_t *in, uint8_t *out, int w, int h, int k,
+                                    const float *weights, int threads)
+{
+    if (w <= 0 || h <= 0 || k <= 0 || (k & 1) == 0)
+        return -1;
+#ifdef _OPENMP
+    if (threads > 0)
+        omp_set_num_threads(threads);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++)
+        gauss_rows(in, out, w, h, k, weights, y, y + 1);
+#else
+    (void)threads;
+    gauss_rows(in, out, w, h, k, weights, 0, h);
+#endif
+    return 0;
+}
+
+ORACLE_API int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* Sobel — src/EdgeDetection/EdgeDetection.cpp:219-240                        */
+/*   filter2D(src, gx, CV_32F, sobel_x); filter2D(src, gy, CV_32F, sobel_y);  */
+/*   magnitude(gx, gy, mag); mag.convertTo(out, CV_8UC1);                     */
+/* Restated OpenCV semantics (documented behaviour, OpenCV itself is absent): */
+/*   filter2D = correlation, anchor at the kernel centre, BORDER_REFLECT_101; */
+/*   magnitude = sqrt(x*x + y*y) in float; convertTo u8 = round-half-to-even  */
+/*   (cvRound) then saturate.  PARITY UNPINNED.                               */
+/* ------------------------------------------------------------------------- */
+static inline int reflect101(int p, int len)
+{
+    /* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
+    if (len == 1)
+        return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0)
+            p = -p;
+        else
+            p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+ORACLE_API int oracle_sobel_gray(const uint8_t *gray, uint8_t *out, int w, int h)
+{
+    if (w <= 0 || h <= 0)
+        return -1;
+    static const float sx[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}};
+    static const float sy[3][3] = {{-1, -2, -1}, {0, 0, 0}, {1, 2, 1}};
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            float gx = 0.0f, gy = 0.0f;
+            for (int ky = -1; ky <= 1; ky++) {
+                int yy = reflect101(y + ky, h);
+                for (int kx = -1; kx <= 1; kx++) {
+                    int xx = reflect101(x + kx, w);
+                    float v = (float)gray[(size_t)yy * w + xx];
+                    gx += v * sx[ky + 1][kx + 1];
+                    gy += v * sy[ky + 1][kx + 1];
+                }
+            }
+            float mag = sqrtf(gx * gx + gy * gy);
+            long r = lrintf(mag); /* round-half-to-even in the default FP mode */
+            out[(size_t)y * w + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+    }
+    return 0;
+}
+
+/* Standalone Sobel on an RGBA buffer.  The reference has no CPU Sobel for RGBA
+ * (it starts from a decoder-gray JPEG, EdgeDetection.cpp:202); the recorded
+ * decision is gray = grayscale.cpp:237 formula, then the above. */
+ORACLE_API int oracle_sobel_rgba(const uint8_t *rgba, uint8_t *out, int w, int h)
+{
+    if (w <= 0 || h <= 0)
+        return -1;
+    uint8_t *g = (uint8_t *)malloc((size_t)w * h);
+    if (!g)
+        return -2;
+    oracle_gray_rgba_1ch(rgba, g, w, h);
+    int rc = oracle_sobel_gray(g, out, w, h);
+    free(g);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Fused pipeline (build-defined; SURVEY.md §8a row "a-pipe"): exactly the    */
+/* composition of the three API calls in buffer mode —                        */
+/*   gray -> (g,g,g,255) RGBA -> Gaussian (all four channels) -> Sobel whose  */
+/*   luminance formula is RE-APPLIED to the blurred (b,b,b) pixel.            */
+/* Implemented literally by chaining the functions above.                     */
+/* ------------------------------------------------------------------------- */
+ORACLE_API int oracle_pipeline_rgba(const uint8_t *rgba, uint8_t *out, int w, int h, int k,
+                                    const float *weights)
+{
+    if (w <= 0 || h <= 0 || k <= 0 || (k & 1) == 0)
+        return -1;
+    size_t n = (size_t)w * h;
+    uint8_t *g4 = (uint8_t *)malloc(n * 4);
+    uint8_t *b4 = (uint8_t *)malloc(n * 4);
+    if (!g4 || !b4) {
+        free(g4);
+        free(b4);
+        return -2;
+    }
+    oracle_gray_rgba(rgba, g4, w, h);
+    gauss_rows(g4, b4, w, h, k, weights, 0, h);
+    int rc = oracle_sobel_rgba(b4, out, w, h);
+    free(g4);
+    free(b4);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic frames: counter hash of               */
+/* (seed, frame, y, x); R,G,B = hash bytes 0..2, A = 255.  mode 1 = smooth    */
+/* gradient + 4 bits of noise (photographic-like, exercises truncation        */
+/* boundaries).  The HIP twin is csrc/synth.hip; both must agree bit-exactly. */
+/* ------------------------------------------------------------------------- */
+static inline uint32_t fmix32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+static inline uint32_t synth_hash(uint32_t seed, uint32_t frame, uint32_t y, uint32_t x)
+{
+    uint32_t h = seed ^ (frame * 0x9E3779B1u);
+    h = fmix32(h ^ (y * 0x85EBCA77u));
+    h = fmix32(h ^ (x * 0xC2B2AE3Du));
+    return h;
+}
+
+ORACLE_API void oracle_synth_rgba(uint8_t *out, int w, int h, int nframes, int first_frame,
+                                  uint32_t seed, int mode)
+{
+    for (int f = 0; f < nframes; f++) {
+        uint8_t *fr = out + (size_t)f * w * h * 4;
+        for (int y = 0; y < h; y++) {
+            for (int x = 0; x < w; x++) {
+                uint32_t hsh = synth_hash(seed, (uint32_t)(first_frame + f), (uint32_t)y, (uint32_t)x);
+                uint8_t *p = fr + ((size_t)y * w + x) * 4;
+                if (mode == 0) {
+                    p[0] = (uint8_t)(hsh & 0xFF);
+                    p[1] = (uint8_t)((hsh >> 8) & 0xFF);
+                    p[2] = (uint8_t)((hsh >> 16) & 0xFF);
+                } else {
+                    int gx = (int)(((uint32_t)x * 255u) / (uint32_t)(w > 1 ? w - 1 : 1));
+                    int gy = (int)(((uint32_t)y * 255u) / (uint32_t)(h > 1 ? h - 1 : 1));
+                    int r = gx + (int)(hsh & 15) - 8;
+                    int g = gy + (int)((hsh >> 8) & 15) - 8;
+                    int b = ((gx + gy) >> 1) + (int)((hsh >> 16) & 15) - 8;
+                    p[0] = (uint8_t)clampi(r, 0, 255);
+                    p[1] = (uint8_t)clampi(g, 0, 255);
+                    p[2] = (uint8_t)clampi(b, 0, 255);
+                }
+                p[3] = 255;
+            }
+        }
+    }
+}
+
+/* Order-independent 64-bit checksum of a byte buffer, defined so that the GPU
+ * can compute it with one atomic add per workgroup and any sharding of frames
+ * over GPUs sums to the same value:  sum over 32-bit words i of
+ * fmix64(word_i + (i << 32)), modulo 2^64 (trailing bytes zero-padded). */
+static inline uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33;
+    k *= 0xFF51AFD7ED558CCDull;
+    k ^= k >> 33;
+    k *= 0xC4CEB9FE1A85EC53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+ORACLE_API uint64_t oracle_checksum(const uint8_t *buf, size_t nbytes, uint64_t index_base)
+{
+    uint64_t acc = 0;
+    size_t nwords = nbytes / 4;
+    for (size_t i = 0; i < nwords; i++) {
+        uint32_t wv;
+        memcpy(&wv, buf + 4 * i, 4);
+        acc += fmix64((uint64_t)wv + ((index_base + i) << 32));
+    }
+    size_t rem = nbytes & 3;
+    if (rem) {
+        uint32_t wv = 0;
+        memcpy(&wv, buf + 4 * nwords, rem);
+        acc += fmix64((uint64_t)wv + ((index_base + nwords) << 32));
+    }
+    return acc;
+}
