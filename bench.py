@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — headline measurement: Mpixels/s of the Gaussian 5x5 (sigma 1.5) on 4K RGBA frames.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path (one batched kernel launch through the
+C-ABI, mi355_filter_dev) over this rank's batch of synthetic frames, which are generated on the GPU
+and resident in HBM before the timed region.  Frames shard by index (rank r owns frames
+[r*F, (r+1)*F)), no pixel ever crosses GPUs; the only collective on the data path's setup is one RCCL
+broadcast of the coefficient table from rank 0.  Weak scaling: F frames per GPU at every N.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+# algorithmic bytes per pixel: what the kernel must read + write, halo re-reads,
+# LDS traffic and cache hits not counted
+ALGO_BPP = {"gauss": 8, "gray": 8, "gray1": 5, "sobel": 5, "pipeline": 5}
+FILTER_ID = {"gray": 0, "gray1": 1, "gauss": 2, "sobel": 3, "pipeline": 4}
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--filter", default="gauss", choices=sorted(FILTER_ID))
+    p.add_argument("--width", type=int, default=3840)
+    p.add_argument("--height", type=int, default=2160)
+    p.add_argument("--frames", type=int, default=64, help="frames per GPU per step (>=32: working set "
+                   "must exceed the 256 MiB Infinity Cache so the kernel streams from HBM)")
+    p.add_argument("--k", type=int, default=5)
+    p.add_argument("--sigma", type=float, default=1.5)
+    p.add_argument("--mode", default="fast", choices=["fast", "exact"])
+    p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def cpu_baseline(args, oracle):
+    """The reference's CPU path (our C restatement, oracle/), timed on this box's host cores on a
+    bounded sample of the same workload.  Test/measurement infrastructure: never on the product path."""
+    if args.filter not in ("gauss", "pipeline", "sobel", "gray", "gray1"):
+        return None
+    w, h = args.width, args.height
+    fn = {
+        "gauss": lambda f, t: oracle.gauss_rgba(f, args.k, args.sigma, threads=t),
+        "pipeline": lambda f, t: oracle.pipeline_rgba(f, args.k, args.sigma),
+        "sobel": lambda f, t: oracle.sobel_rgba(f),
+        "gray": lambda f, t: oracle.gray_rgba(f),
+        "gray1": lambda f, t: oracle.gray_rgba_1ch(f),
+    }[args.filter]
+    frames = oracle.synth_rgba(w, h, 2, first_frame=0, seed=0x5EED, mode=args.synth_mode)
+    fn(frames[0][: min(h, 64)], 1)  # warm the code path
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(frames[n % 2], 1)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= args.cpu_seconds or n >= 64:
+            break
+    out = {"value": n * w * h / el / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+           "sample": "%d x %dx%d synthetic frame(s), %s k=%d sigma=%g, 1 thread (the reference CPU path is "
+                     "single-threaded), %.1f s" % (n, w, h, args.filter, args.k, args.sigma, el)}
+    if args.filter == "gauss":
+        cores = oracle.max_threads()
+        fn(frames[0], cores)
+        m, t0 = 0, time.perf_counter()
+        while True:
+            fn(frames[m % 2], cores)
+            m += 1
+            el = time.perf_counter() - t0
+            if el >= args.cpu_seconds / 2 or m >= 256:
+                break
+        out["all_cores"] = {"value": m * w * h / el / 1e6, "cores": cores,
+                            "sample": "%d frames, OpenMP rows, %.1f s" % (m, el)}
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    pkg = entry.load_package()
+    # launch on torch's current stream so torch's allocator and the barrier below order with the kernels
+    stream = torch.cuda.current_stream(dev)
+    ctx = pkg.Context(local_rank, stream=stream.cuda_stream)
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT if args.mode == "exact" else pkg.GAUSS_FAST)
+
+    w, h, F = args.width, args.height, args.frames
+    filt = FILTER_ID[args.filter]
+    out_bpp = pkg.imgfilter.OUT_BPP[filt]
+    d_in = torch.empty((F, h, w, 4), dtype=torch.uint8, device=dev)
+    d_out = torch.empty((F, h, w, out_bpp), dtype=torch.uint8, device=dev)
+    first_frame = rank * F
+    ctx.synth_dev(d_in.data_ptr(), w, h, F, first_frame=first_frame, seed=0x5EED, mode=args.synth_mode)
+
+    # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes
+    if args.filter in ("gauss", "pipeline"):
+        table = torch.zeros(args.k * args.k, dtype=torch.float32, device=dev)
+        if rank == 0:
+            table.copy_(torch.from_numpy(pkg.gauss_weights(args.k, args.sigma).reshape(-1)))
+        if dist is not None:
+            dist.broadcast(table, src=0)
+        ctx.set_gauss_weights(args.k, args.sigma, table.cpu().numpy())
+
+    def step():
+        ctx.filter_dev(filt, d_in.data_ptr(), d_out.data_ptr(), w, h, F, args.k, args.sigma)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    ctx.timer_begin()           # hipEventRecord on the stream the kernels are launched on
+    for _ in range(args.steps):
+        step()
+    kernel_ms = ctx.timer_end()  # hipEventRecord + hipEventSynchronize + hipEventElapsedTime
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # one launch per step: average launch duration from the HIP events around the timed region
+    avg_launch_ms = kernel_ms / args.steps
+    checksum = ctx.checksum_dev(d_out.data_ptr(), d_out.numel(), index_base=first_frame * (w * h * out_bpp // 4))
+
+    t_max, ms_max, ck_sum = elapsed, avg_launch_ms, checksum
+    if dist is not None:
+        t = torch.tensor([elapsed, avg_launch_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_max, ms_max = float(t[0]), float(t[1])
+        # 64-bit modular sum of per-rank checksums, carried as two 32-bit halves in int64
+        c = torch.tensor([checksum & 0xFFFFFFFF, checksum >> 32], dtype=torch.int64, device=dev)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        ck_sum = (int(c[0]) + (int(c[1]) << 32)) & 0xFFFFFFFFFFFFFFFF
+
+    if rank == 0:
+        px_per_launch = F * w * h
+        total_px = world * px_per_launch * args.steps
+        algo_bytes = ALGO_BPP[args.filter] * px_per_launch
+        achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                key = "%s_%dx%d_f%d_k%d" % (args.filter, w, h, F, args.k)
+                if key in pmc:
+                    traffic = pmc[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpixels/s (Gaussian 5x5, 4K RGBA)" if (args.filter, args.k, w, h) == ("gauss", 5, 3840, 2160)
+                      else "Mpixels/s (%s k=%d, %dx%d RGBA)" % (args.filter, args.k, w, h),
+            "value": total_px / t_max / 1e6,
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": t_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 in/out, f32 accumulate" if args.filter in ("gauss", "pipeline") else "u8 in/out, f64 luminance",
+            "data": "synthetic (device-generated counter-hash frames, resident in HBM before timing)",
+            "config": {"workload": "%s k=%d sigma=%g, %dx%d RGBA, %d frames/GPU/step, mode=%s" %
+                                   (args.filter, args.k, args.sigma, w, h, F, args.mode),
+                       "frames_per_gpu": F, "width": w, "height": h, "parallelism": "frames sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": avg_launch_ms, "avg_launch_ms_max_over_ranks": ms_max,
+                         "kernel": "see profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
+            "checksum": "%016x" % ck_sum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, entry.load_oracle())
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

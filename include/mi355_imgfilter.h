@@ -1,0 +1,175 @@
+/*
+ * mi355_imgfilter.h — C-ABI of libmi355_imgfilter.so, the MI355X (gfx950) image-filter hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Every entry point
+ * names the reference interface it replaces (paths relative to the reference repository root;
+ * RT/ = src/RealtimeImageProcessing/).  The C++ classes in host/ (Controller, ProgramHandler)
+ * forward to these functions; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Pixel layout everywhere: interleaved 8-bit RGBA, row-major, tightly packed (stride = 4*width),
+ * as produced by cv::cvtColor(BGR2RGBA) at RT/src/ProgramHandler.cpp:127.
+ *
+ * Conventions: every function returns MI355_OK (0) or a negative MI355_ERR_* code; nothing throws,
+ * nothing calls exit().  A context is bound to one GPU and one HIP stream and must be used from one
+ * host thread at a time (the reference Controller is single-threaded too: include/Controller.hpp:50).
+ * There is no CPU fallback: without a usable gfx950 device mi355_ctx_create fails.
+ */
+#ifndef MI355_IMGFILTER_H
+#define MI355_IMGFILTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_OK 0
+#define MI355_ERR_BAD_ARG (-1)     /* null pointer, non-positive size, even/oversized kernel_size */
+#define MI355_ERR_HIP (-2)         /* a HIP runtime call failed; see mi355_last_hip_error */
+#define MI355_ERR_NO_DEVICE (-3)   /* no GPU / device index out of range */
+#define MI355_ERR_UNSUPPORTED (-4) /* request outside what the kernels implement */
+#define MI355_ERR_NOMEM (-5)
+
+/* Largest Gaussian kernel_size accepted (odd).  The reference's own default is 17
+ * (include/ProgramHandler.hpp:9). */
+#define MI355_MAX_GAUSS_K 63
+
+/* Gaussian arithmetic selection (mi355_ctx_set_gauss_mode):
+ *   FAST  — separable, FMA, vertical pass then horizontal pass; within +-1 LSB per channel of the
+ *           reference CPU path (src/GaussianBlur/GaussianBlur.cpp:234-261).  Default.
+ *   EXACT — the reference CPU path's own arithmetic (k*k taps, ky outer / kx inner, separate float
+ *           multiply and add, truncation): bit-identical output, several times slower. */
+#define MI355_GAUSS_FAST 0
+#define MI355_GAUSS_EXACT 1
+
+typedef struct mi355_ctx mi355_ctx;
+
+/* ---- context -------------------------------------------------------------------------------
+ * Replaces the OpenCL bootstrap of Controller (RT/src/Controller.cpp:13-197: GetPlatforms,
+ * GetDevices, CreateContext, CreateCommandQueue w/ CL_QUEUE_PROFILING_ENABLE :118, CreateProgram,
+ * CreateKernel).  One context = {HIP device, stream, timing events, pooled device/pinned staging
+ * buffers, cached Gaussian coefficient table}.  The reference allocates and frees device buffers on
+ * every call (:234-244, :515-516); the pool here grows to the largest frame seen and is reused. */
+int mi355_device_count(int* count);
+int mi355_ctx_create(int device, mi355_ctx** out);
+/* Same, but launches on a caller-owned hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)
+ * so the caller's stream-ordered allocator and events see the kernels. */
+int mi355_ctx_create_on_stream(int device, void* hip_stream, mi355_ctx** out);
+int mi355_ctx_destroy(mi355_ctx* ctx);
+int mi355_ctx_device_name(mi355_ctx* ctx, char* buf, size_t buflen);
+int mi355_sync(mi355_ctx* ctx);
+int mi355_last_hip_error(mi355_ctx* ctx);
+const char* mi355_strerror(int code);
+
+int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
+
+/* Kernel selection for the FAST Gaussian (a tuning / test knob; results are bit-identical):
+ *   AUTO — register-resident sliding-window kernel when k in {3,5,7,9}, width % 4 == 0 and both
+ *          buffers are 16-byte aligned; the LDS-tiled kernel otherwise.
+ *   TILE — always the LDS-tiled kernel. */
+#define MI355_GAUSS_IMPL_AUTO 0
+#define MI355_GAUSS_IMPL_TILE 1
+int mi355_ctx_set_gauss_impl(mi355_ctx* ctx, int impl);
+
+/* ---- Gaussian coefficients -----------------------------------------------------------------
+ * mi355_gauss_weights replaces Controller::_GenerateGaussianKernelBuffers
+ * (RT/src/Controller.cpp:352-372 = src/GaussianBlur/src/Controller.cpp:342-362): k*k floats,
+ * row-major [(y+k/2)*k + (x+k/2)], same promotion chain (float argument, exp in double, divide by
+ * the double 2*M_PI*sigma^2, store float, float running sum, divide by it).  Pure host function.
+ * The reference regenerates and re-uploads the table on every frame (:667,:674, leaking the
+ * cl_mem); here the table is cached per (k, sigma) inside the context.
+ *
+ * mi355_ctx_set_gauss_weights installs an externally supplied k*k table (multi-GPU mode: rank 0
+ * generates it, RCCL broadcasts it, every rank installs the same bytes) for the given (k, sigma)
+ * key; later calls with that (k, sigma) use it instead of regenerating. */
+int mi355_gauss_weights(int k, float sigma, float* out_k2);
+int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, const float* w_k2);
+
+/* ---- host-buffer calls: what Controller::PerformCL* forwards to ----------------------------
+ * Each call = H2D, one kernel, D2H, synchronous on return, exactly like the reference
+ * (RT/src/Controller.cpp:429-519, :521-613, :615-744).  prof_ns (may be NULL) receives the six
+ * timestamps the reference appends to profiling_events via _profileEvent (:66-74, :471,:489,:513):
+ * write-start, write-end, kernel-start, kernel-end, read-start, read-end, in ns on one clock.
+ *
+ * mi355_gray_rgba8     replaces PerformCLImageGrayscaling (buffer mode): out = w*h*4 bytes,
+ *                      (g,g,g,255) per pixel.  g follows the CPU path src/Grayscale/grayscale.cpp:237
+ *                      (double arithmetic, truncation) bit-exactly — not the float kernel
+ *                      RT/kernel/grayscale_base.cl:14.
+ * mi355_gray1_rgba8    same gray value, one byte per pixel (the CPU path's output shape,
+ *                      grayscale.cpp:216).
+ * mi355_gauss_rgba8    replaces PerformCLGaussianBlur: out = w*h*4 bytes; clamp-to-edge taps, all
+ *                      four channels, truncation; semantics of the CPU path GaussianBlur.cpp:234-261
+ *                      (no division by the accumulated weight, unlike gaussian_base.cl:48).
+ * mi355_sobel_rgba8    replaces PerformCLImageEdgeDetection: out = w*h bytes.  Semantics of the CPU
+ *                      path src/EdgeDetection/EdgeDetection.cpp:219-240 applied to
+ *                      gray = grayscale.cpp:237 of each pixel: 3x3 correlation, BORDER_REFLECT_101,
+ *                      float magnitude, round-half-even, saturate — every pixel written (the OpenCL
+ *                      kernel edge_base.cl:12 leaves the border unwritten).
+ * mi355_pipeline_rgba8 fused gray -> Gaussian -> Sobel, defined as the exact composition of the three
+ *                      calls above (SURVEY.md §8a "a-pipe"): out = w*h bytes. */
+int mi355_gray_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_rgba, int w, int h,
+                     uint64_t prof_ns[6]);
+int mi355_gray1_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_gray, int w, int h,
+                      uint64_t prof_ns[6]);
+int mi355_gauss_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_rgba, int w, int h, int k,
+                      float sigma, uint64_t prof_ns[6]);
+int mi355_sobel_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_gray, int w, int h,
+                      uint64_t prof_ns[6]);
+int mi355_pipeline_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_gray, int w, int h, int k,
+                         float sigma, uint64_t prof_ns[6]);
+
+/* Batched host-buffer form: nframes frames back to back in `rgba` and in `out`; one H2D, one launch
+ * (grid.z-style frame index), one D2H.  filter: MI355_FILTER_*. */
+#define MI355_FILTER_GRAY 0     /* RGBA -> RGBA (g,g,g,255) */
+#define MI355_FILTER_GRAY1 1    /* RGBA -> 1 byte            */
+#define MI355_FILTER_GAUSS 2    /* RGBA -> RGBA              */
+#define MI355_FILTER_SOBEL 3    /* RGBA -> 1 byte            */
+#define MI355_FILTER_PIPELINE 4 /* RGBA -> 1 byte            */
+int mi355_filter_batched(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h,
+                         int nframes, int k, float sigma, uint64_t prof_ns[6]);
+/* bytes per output pixel of a filter (4 or 1), or MI355_ERR_BAD_ARG */
+int mi355_filter_out_bpp(int filter);
+
+/* ---- device-resident calls -----------------------------------------------------------------
+ * d_in / d_out are device pointers on the context's GPU holding nframes tightly packed frames;
+ * the call enqueues the kernel(s) on the context's stream and returns without synchronising.
+ * These are what a caller that already owns device memory (torch, a capture pipeline) binds, and
+ * what the roofline measurement times (no PCIe in the timed region). */
+int mi355_gray_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
+int mi355_gray1_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
+int mi355_gauss_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes,
+                          int k, float sigma);
+int mi355_sobel_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
+int mi355_pipeline_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes,
+                             int k, float sigma);
+int mi355_filter_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int w, int h,
+                     int nframes, int k, float sigma);
+
+/* Synthetic frames: px = hash(seed, first_frame + f, y, x), A = 255; mode 1 = smooth
+ * gradient + 4-bit noise.  Bit-identical to oracle_synth_rgba. */
+int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes, int first_frame,
+                          uint32_t seed, int mode);
+/* Order-independent 64-bit checksum of nbytes at d_buf (sum of per-word hashes mod 2^64; word i is
+ * hashed with index index_base + i), written to *out after synchronising the stream.  Sharding a
+ * batch over GPUs and adding the per-rank values gives the single-GPU value. */
+int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbytes, uint64_t index_base,
+                       uint64_t* out);
+
+/* ---- device memory + timing helpers for hosts that do not bring their own ------------------- */
+int mi355_dev_alloc(mi355_ctx* ctx, size_t nbytes, void** d_ptr);
+int mi355_dev_free(mi355_ctx* ctx, void* d_ptr);
+int mi355_copy_h2d(mi355_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
+int mi355_copy_d2h(mi355_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
+/* hipEvent pair on the context's stream: begin records, end records + synchronises and returns the
+ * elapsed milliseconds.  This is the HIP-event timing the roofline figure is computed from. */
+int mi355_timer_begin(mi355_ctx* ctx);
+int mi355_timer_end(mi355_ctx* ctx, float* elapsed_ms);
+
+/* Library build info: "gfx950;<git-or-date>" */
+const char* mi355_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_IMGFILTER_H */

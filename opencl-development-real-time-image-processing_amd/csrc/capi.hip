@@ -1,0 +1,629 @@
+// capi.hip — the C-ABI of libmi355_imgfilter.so (include/mi355_imgfilter.h): context, pooled
+// buffers, coefficient cache, HIP-event profiling, and the host-buffer / device-resident entry
+// points.  No CPU fallback anywhere: every filter call ends in a gfx950 kernel launch or an error.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <new>
+#include <vector>
+
+#include "../../include/mi355_imgfilter.h"
+#include "kernels.hpp"
+
+using namespace mi355;
+
+namespace {
+
+struct CoefEntry {
+    int k;
+    uint32_t sigma_bits;
+    GaussCoef coef;
+    float* d_buf;  // [k*k w2d][k w1d]
+};
+
+}  // namespace
+
+struct mi355_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[6] = {};
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    void* d_in = nullptr;
+    size_t d_in_cap = 0;
+    void* d_out = nullptr;
+    size_t d_out_cap = 0;
+    unsigned long long* d_acc = nullptr;
+    int gauss_mode = MI355_GAUSS_FAST;
+    int gauss_impl = MI355_GAUSS_IMPL_AUTO;
+    int last_hip = 0;
+    char name[256] = {};
+    std::vector<CoefEntry> coefs;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                     \
+    do {                                       \
+        hipError_t e__ = (expr);               \
+        if (e__ != hipSuccess) {               \
+            if (ctx)                           \
+                (ctx)->last_hip = (int)e__;    \
+            return MI355_ERR_HIP;              \
+        }                                      \
+    } while (0)
+
+uint64_t now_ns()
+{
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+uint32_t fbits(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+bool valid_k(int k) { return k >= 1 && k <= MI355_MAX_GAUSS_K && (k & 1) == 1; }
+bool valid_sigma(float s) { return std::isfinite(s) && s > 0.0f; }
+
+// Controller::_GenerateGaussianKernelBuffers, RT/src/Controller.cpp:352-372.
+// `exp` there binds to ::exp(double); the float argument is widened.
+void gen_weights(int k, float sigma, float* out)
+{
+    const int half = k / 2;
+    float sum = 0.0f;
+    for (int y = -half; y <= half; y++) {
+        for (int x = -half; x <= half; x++) {
+            const float arg = -(x * x + y * y) / (2 * sigma * sigma);
+            const float value = (float)(std::exp((double)arg) / (2 * M_PI * sigma * sigma));
+            out[(y + half) * k + (x + half)] = value;
+            sum += value;
+        }
+    }
+    for (int i = 0; i < k * k; i++)
+        out[i] /= sum;
+}
+
+// separable factor of the table for the FAST arithmetic: rowsum / sqrt(total), in double
+void separable_factor(int k, const float* w2d, float* w1d)
+{
+    double tot = 0.0;
+    std::vector<double> rs(k, 0.0);
+    for (int i = 0; i < k; i++) {
+        for (int j = 0; j < k; j++)
+            rs[i] += (double)w2d[i * k + j];
+        tot += rs[i];
+    }
+    const double s = std::sqrt(tot);
+    for (int i = 0; i < k; i++)
+        w1d[i] = (float)(rs[i] / s);
+}
+
+int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const GaussCoef** out)
+{
+    CoefEntry* slot = nullptr;
+    for (auto& e : ctx->coefs)
+        if (e.k == k && e.sigma_bits == fbits(sigma))
+            slot = &e;
+    if (!slot) {
+        CoefEntry e{};
+        e.k = k;
+        e.sigma_bits = fbits(sigma);
+        HIP_TRY(ctx, hipMalloc((void**)&e.d_buf, sizeof(float) * (size_t)(k * k + k)));
+        ctx->coefs.push_back(e);
+        slot = &ctx->coefs.back();
+    }
+    std::vector<float> host((size_t)k * k + k);
+    std::memcpy(host.data(), w2d, sizeof(float) * (size_t)k * k);
+    separable_factor(k, w2d, host.data() + (size_t)k * k);
+    // blocking copy from pageable memory: the table is live on the device when this returns
+    HIP_TRY(ctx, hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    slot->coef.k = k;
+    slot->coef.d_w2d = slot->d_buf;
+    slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
+    std::memset(slot->coef.h_w1d, 0, sizeof(slot->coef.h_w1d));
+    std::memcpy(slot->coef.h_w1d, host.data() + (size_t)k * k, sizeof(float) * k);
+    if (out)
+        *out = &slot->coef;
+    return MI355_OK;
+}
+
+int get_coef(mi355_ctx* ctx, int k, float sigma, const GaussCoef** out)
+{
+    for (auto& e : ctx->coefs)
+        if (e.k == k && e.sigma_bits == fbits(sigma)) {
+            *out = &e.coef;
+            return MI355_OK;
+        }
+    std::vector<float> w((size_t)k * k);
+    gen_weights(k, sigma, w.data());
+    return install_coef(ctx, k, sigma, w.data(), out);
+}
+
+int ensure(mi355_ctx* ctx, void** p, size_t* cap, size_t need)
+{
+    if (*cap >= need)
+        return MI355_OK;
+    if (*p) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    // grow geometrically so a stream of slightly different frame sizes does not reallocate each time
+    size_t want = need + need / 4;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        e = hipMalloc(p, need);
+        want = need;
+    }
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        *p = nullptr;
+        return MI355_ERR_NOMEM;
+    }
+    *cap = want;
+    return MI355_OK;
+}
+
+bool filter_needs_gauss(int f) { return f == MI355_FILTER_GAUSS || f == MI355_FILTER_PIPELINE; }
+
+int check_frames(const void* in, const void* out, int w, int h, int nframes)
+{
+    if (!in || !out || w <= 0 || h <= 0 || nframes <= 0)
+        return MI355_ERR_BAD_ARG;
+    // 2^31 tiles / 2^40 bytes is far beyond 288 GB of HBM; reject before any size_t arithmetic wraps
+    const double px = (double)w * (double)h * (double)nframes;
+    if (px > 6.0e10)
+        return MI355_ERR_BAD_ARG;
+    return MI355_OK;
+}
+
+int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int w, int h, int nframes,
+                 int k, float sigma)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(d_in, d_out, w, h, nframes);
+    if (rc != MI355_OK)
+        return rc;
+    if (reinterpret_cast<uintptr_t>(d_in) & 3u)
+        return MI355_ERR_BAD_ARG;  // RGBA pixels are accessed as dwords
+    const bool rgba_out = (filter == MI355_FILTER_GRAY || filter == MI355_FILTER_GAUSS);
+    if (rgba_out && (reinterpret_cast<uintptr_t>(d_out) & 3u))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const GaussCoef* coef = nullptr;
+    if (filter_needs_gauss(filter)) {
+        if (!valid_k(k) || !valid_sigma(sigma))
+            return MI355_ERR_BAD_ARG;
+        rc = get_coef(ctx, k, sigma, &coef);
+        if (rc != MI355_OK)
+            return rc;
+    }
+    const uint8_t* in = static_cast<const uint8_t*>(d_in);
+    uint8_t* out = static_cast<uint8_t*>(d_out);
+    const bool exact = ctx->gauss_mode == MI355_GAUSS_EXACT;
+    hipError_t e;
+    switch (filter) {
+    case MI355_FILTER_GRAY:
+        e = launch_gray(ctx->stream, in, out, w, h, nframes, false);
+        break;
+    case MI355_FILTER_GRAY1:
+        e = launch_gray(ctx->stream, in, out, w, h, nframes, true);
+        break;
+    case MI355_FILTER_GAUSS:
+        e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->gauss_impl);
+        break;
+    case MI355_FILTER_SOBEL:
+        e = launch_sobel(ctx->stream, in, out, w, h, nframes);
+        break;
+    case MI355_FILTER_PIPELINE:
+        e = launch_pipeline(ctx->stream, in, out, w, h, nframes, *coef, exact);
+        break;
+    default:
+        return MI355_ERR_BAD_ARG;
+    }
+    HIP_TRY(ctx, e);
+    return MI355_OK;
+}
+
+// H2D, kernel, D2H with the reference's six profiling timestamps (RT/src/Controller.cpp:66-74)
+int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w, int h, int nframes,
+             int k, float sigma, uint64_t prof_ns[6])
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    const int bpp = mi355_filter_out_bpp(filter);
+    if (bpp < 0)
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(in, out, w, h, nframes);
+    if (rc != MI355_OK)
+        return rc;
+    if (filter_needs_gauss(filter) && (!valid_k(k) || !valid_sigma(sigma)))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h * nframes;
+    const size_t in_bytes = npx * 4, out_bytes = npx * (size_t)bpp;
+    rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
+    if (rc != MI355_OK)
+        return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
+    if (rc != MI355_OK)
+        return rc;
+    if (filter_needs_gauss(filter)) {
+        // build/upload the coefficient table outside the timed write/kernel/read window
+        const GaussCoef* coef = nullptr;
+        rc = get_coef(ctx, k, sigma, &coef);
+        if (rc != MI355_OK)
+            return rc;
+    }
+    hipStream_t s = ctx->stream;
+    const uint64_t host0 = now_ns();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    rc = dispatch_dev(ctx, filter, ctx->d_in, ctx->d_out, w, h, nframes, k, sigma);
+    if (rc != MI355_OK)
+        return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (prof_ns) {
+        prof_ns[0] = host0;
+        for (int i = 1; i < 6; i++) {
+            float ms = 0.0f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[i]));
+            prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
+        }
+    }
+    return MI355_OK;
+}
+
+int create_common(int device, hipStream_t stream, bool own, mi355_ctx** out)
+{
+    if (!out)
+        return MI355_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return MI355_ERR_NO_DEVICE;
+    if (device < 0 || device >= n)
+        return MI355_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return MI355_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return MI355_ERR_UNSUPPORTED;  // the code objects in this library are gfx950 only
+    mi355_ctx* ctx = new (std::nothrow) mi355_ctx();
+    if (!ctx)
+        return MI355_ERR_NOMEM;
+    ctx->device = device;
+    std::snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    bool ok = hipSetDevice(device) == hipSuccess;
+    if (ok && own)
+        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+    ctx->stream = stream;
+    ctx->own_stream = own && ok;
+    for (int i = 0; ok && i < 6; i++)
+        ok = hipEventCreate(&ctx->ev[i]) == hipSuccess;
+    ok = ok && hipEventCreate(&ctx->t0) == hipSuccess && hipEventCreate(&ctx->t1) == hipSuccess;
+    ok = ok && hipMalloc((void**)&ctx->d_acc, sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        mi355_ctx_destroy(ctx);
+        return MI355_ERR_HIP;
+    }
+    *out = ctx;
+    return MI355_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+#define MI355_API __attribute__((visibility("default")))
+
+MI355_API int mi355_device_count(int* count)
+{
+    if (!count)
+        return MI355_ERR_BAD_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        n = 0;
+    *count = n;
+    return MI355_OK;
+}
+
+MI355_API int mi355_ctx_create(int device, mi355_ctx** out)
+{
+    return create_common(device, nullptr, true, out);
+}
+
+MI355_API int mi355_ctx_create_on_stream(int device, void* hip_stream, mi355_ctx** out)
+{
+    return create_common(device, static_cast<hipStream_t>(hip_stream), false, out);
+}
+
+MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->coefs)
+        (void)hipFree(e.d_buf);
+    if (ctx->d_in)
+        (void)hipFree(ctx->d_in);
+    if (ctx->d_out)
+        (void)hipFree(ctx->d_out);
+    if (ctx->d_acc)
+        (void)hipFree(ctx->d_acc);
+    for (auto& ev : ctx->ev)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    if (ctx->t0)
+        (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1)
+        (void)hipEventDestroy(ctx->t1);
+    if (ctx->own_stream && ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MI355_OK;
+}
+
+MI355_API int mi355_ctx_device_name(mi355_ctx* ctx, char* buf, size_t buflen)
+{
+    if (!ctx || !buf || buflen == 0)
+        return MI355_ERR_BAD_ARG;
+    std::snprintf(buf, buflen, "%s", ctx->name);
+    return MI355_OK;
+}
+
+MI355_API int mi355_sync(mi355_ctx* ctx)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+MI355_API int mi355_last_hip_error(mi355_ctx* ctx) { return ctx ? ctx->last_hip : 0; }
+
+MI355_API const char* mi355_strerror(int code)
+{
+    switch (code) {
+    case MI355_OK: return "ok";
+    case MI355_ERR_BAD_ARG: return "bad argument";
+    case MI355_ERR_HIP: return "HIP runtime error";
+    case MI355_ERR_NO_DEVICE: return "no such GPU";
+    case MI355_ERR_UNSUPPORTED: return "unsupported (library is built for gfx950 only)";
+    case MI355_ERR_NOMEM: return "out of memory";
+    default: return "unknown error";
+    }
+}
+
+MI355_API int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode)
+{
+    if (!ctx || (mode != MI355_GAUSS_FAST && mode != MI355_GAUSS_EXACT))
+        return MI355_ERR_BAD_ARG;
+    ctx->gauss_mode = mode;
+    return MI355_OK;
+}
+
+MI355_API int mi355_ctx_set_gauss_impl(mi355_ctx* ctx, int impl)
+{
+    if (!ctx || (impl != MI355_GAUSS_IMPL_AUTO && impl != MI355_GAUSS_IMPL_TILE))
+        return MI355_ERR_BAD_ARG;
+    ctx->gauss_impl = impl;
+    return MI355_OK;
+}
+
+MI355_API int mi355_gauss_weights(int k, float sigma, float* out_k2)
+{
+    if (!out_k2 || !valid_k(k) || !valid_sigma(sigma))
+        return MI355_ERR_BAD_ARG;
+    gen_weights(k, sigma, out_k2);
+    return MI355_OK;
+}
+
+MI355_API int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, const float* w_k2)
+{
+    if (!ctx || !w_k2 || !valid_k(k) || !valid_sigma(sigma))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // a kernel still in flight may be reading the previous table of this key
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return install_coef(ctx, k, sigma, w_k2, nullptr);
+}
+
+MI355_API int mi355_filter_out_bpp(int filter)
+{
+    switch (filter) {
+    case MI355_FILTER_GRAY:
+    case MI355_FILTER_GAUSS: return 4;
+    case MI355_FILTER_GRAY1:
+    case MI355_FILTER_SOBEL:
+    case MI355_FILTER_PIPELINE: return 1;
+    default: return MI355_ERR_BAD_ARG;
+    }
+}
+
+MI355_API int mi355_gray_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out, int w, int h,
+                               uint64_t prof_ns[6])
+{
+    return run_host(ctx, MI355_FILTER_GRAY, rgba, out, w, h, 1, 0, 0.0f, prof_ns);
+}
+
+MI355_API int mi355_gray1_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out, int w, int h,
+                                uint64_t prof_ns[6])
+{
+    return run_host(ctx, MI355_FILTER_GRAY1, rgba, out, w, h, 1, 0, 0.0f, prof_ns);
+}
+
+MI355_API int mi355_gauss_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out, int w, int h, int k,
+                                float sigma, uint64_t prof_ns[6])
+{
+    return run_host(ctx, MI355_FILTER_GAUSS, rgba, out, w, h, 1, k, sigma, prof_ns);
+}
+
+MI355_API int mi355_sobel_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out, int w, int h,
+                                uint64_t prof_ns[6])
+{
+    return run_host(ctx, MI355_FILTER_SOBEL, rgba, out, w, h, 1, 0, 0.0f, prof_ns);
+}
+
+MI355_API int mi355_pipeline_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out, int w, int h,
+                                   int k, float sigma, uint64_t prof_ns[6])
+{
+    return run_host(ctx, MI355_FILTER_PIPELINE, rgba, out, w, h, 1, k, sigma, prof_ns);
+}
+
+MI355_API int mi355_filter_batched(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w,
+                                   int h, int nframes, int k, float sigma, uint64_t prof_ns[6])
+{
+    return run_host(ctx, filter, rgba, out, w, h, nframes, k, sigma, prof_ns);
+}
+
+MI355_API int mi355_filter_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int w, int h,
+                               int nframes, int k, float sigma)
+{
+    if (mi355_filter_out_bpp(filter) < 0)
+        return MI355_ERR_BAD_ARG;
+    return dispatch_dev(ctx, filter, d_in, d_out, w, h, nframes, k, sigma);
+}
+
+MI355_API int mi355_gray_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h,
+                                   int nframes)
+{
+    return dispatch_dev(ctx, MI355_FILTER_GRAY, d_in, d_out, w, h, nframes, 0, 0.0f);
+}
+
+MI355_API int mi355_gray1_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h,
+                                    int nframes)
+{
+    return dispatch_dev(ctx, MI355_FILTER_GRAY1, d_in, d_out, w, h, nframes, 0, 0.0f);
+}
+
+MI355_API int mi355_gauss_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h,
+                                    int nframes, int k, float sigma)
+{
+    return dispatch_dev(ctx, MI355_FILTER_GAUSS, d_in, d_out, w, h, nframes, k, sigma);
+}
+
+MI355_API int mi355_sobel_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h,
+                                    int nframes)
+{
+    return dispatch_dev(ctx, MI355_FILTER_SOBEL, d_in, d_out, w, h, nframes, 0, 0.0f);
+}
+
+MI355_API int mi355_pipeline_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h,
+                                       int nframes, int k, float sigma)
+{
+    return dispatch_dev(ctx, MI355_FILTER_PIPELINE, d_in, d_out, w, h, nframes, k, sigma);
+}
+
+MI355_API int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes,
+                                    int first_frame, uint32_t seed, int mode)
+{
+    if (!ctx || (mode != 0 && mode != 1))
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(d_out, d_out, w, h, nframes);
+    if (rc != MI355_OK)
+        return rc;
+    if (reinterpret_cast<uintptr_t>(d_out) & 3u)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, launch_synth(ctx->stream, static_cast<uint8_t*>(d_out), w, h, nframes, first_frame, seed,
+                              mode));
+    return MI355_OK;
+}
+
+MI355_API int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbytes, uint64_t index_base,
+                                 uint64_t* out)
+{
+    if (!ctx || !d_buf || !out)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_checksum(ctx->stream, static_cast<const uint8_t*>(d_buf), nbytes, index_base,
+                                 ctx->d_acc));
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_acc, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *out = (uint64_t)v;
+    return MI355_OK;
+}
+
+MI355_API int mi355_dev_alloc(mi355_ctx* ctx, size_t nbytes, void** d_ptr)
+{
+    if (!ctx || !d_ptr || nbytes == 0)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, nbytes);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        *d_ptr = nullptr;
+        return MI355_ERR_NOMEM;
+    }
+    return MI355_OK;
+}
+
+MI355_API int mi355_dev_free(mi355_ctx* ctx, void* d_ptr)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    if (!d_ptr)
+        return MI355_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return MI355_OK;
+}
+
+MI355_API int mi355_copy_h2d(mi355_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes)
+{
+    if (!ctx || !d_dst || !h_src)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+MI355_API int mi355_copy_d2h(mi355_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes)
+{
+    if (!ctx || !h_dst || !d_src)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MI355_OK;
+}
+
+MI355_API int mi355_timer_begin(mi355_ctx* ctx)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->t0, ctx->stream));
+    return MI355_OK;
+}
+
+MI355_API int mi355_timer_end(mi355_ctx* ctx, float* elapsed_ms)
+{
+    if (!ctx || !elapsed_ms)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->t1));
+    HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return MI355_OK;
+}
+
+MI355_API const char* mi355_build_info(void) { return "gfx950;" __DATE__ " " __TIME__; }
+
+}  // extern "C"

@@ -1,0 +1,17 @@
+// gauss.hip — Gaussian blur dispatch: picks the kernel for (k, width, mode).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                        int nframes, const GaussCoef& coef, bool exact, int impl)
+{
+    // EXACT arithmetic exists only in the tiled kernel; the sliding-window kernel covers the FAST
+    // arithmetic for the small kernels and 4-pixel-aligned rows (every config in BASELINE.json).
+    if (!exact && impl != 1 && gauss_slide_supported(d_in, d_out, w, h, coef.k))
+        return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef);
+    return launch_gauss_tile(stream, d_in, d_out, w, h, nframes, coef, exact);
+}
+
+}  // namespace mi355

@@ -1,0 +1,237 @@
+// gauss_slide.hip — the headline kernel: separable Gaussian blur of RGBA8 frames for k = 3, 5, 7, 9,
+// register-resident sliding window, one wavefront per image strip.  gfx950 only.
+//
+// Replaces kernel `gaussian_blur` (RT/kernel/gaussian_base.cl:1-50), semantics of the reference CPU
+// path src/GaussianBlur/GaussianBlur.cpp:234-261 (clamp-to-edge, 4 channels, truncation), FAST
+// arithmetic (within 1 LSB per channel; canonical op order shared with gauss_tile.hip, so the two
+// kernels agree bit for bit).
+//
+// Mapping (DESIGN.md "Gaussian, sliding window"):
+//  * a lane owns 4 consecutive pixels (one 16-byte global_load_dwordx4 / global_store_dwordx4);
+//    a wave owns a vertical strip of up to 62 such lanes plus one halo lane on each side, and walks
+//    down a band of rows.  Every input row of the band is loaded exactly once by exactly one
+//    coalesced 1-KiB wave access; K rows are kept in flight per wave (prefetch ring in VGPRs).
+//  * vertical pass first, in registers: K running accumulators per lane (one per pending output
+//    row), each new row is converted once (v_cvt_f32_ubyteN) and folded into all K of them;
+//    the accumulator that just received its last tap is the finished vertical sum `v`.
+//  * horizontal pass on `v`: taps that fall in the neighbouring lane are read through DPP
+//    (wave_shr:1 / wave_shl:1) — no LDS, no barrier, no shuffle instruction.
+//  * clamp-to-edge: rows by clamping the (wave-uniform) row index; columns by replicating the edge
+//    pixel into the halo lane at load time, so the arithmetic itself has no border cases.
+// Algorithmic bytes: 8 B/px.  Extra traffic: halo lanes (2/62 of the loads, L2/MALL hits) and 2R
+// warm-up rows per band.  VALU: 2*K FMA per channel + 1 cvt in + 1 cvt/pack out.  Bound: HBM.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kLanesOutMax = 62;  // 64 lanes minus one halo lane per side
+constexpr int kWavesPerBlock = 4;
+
+template <int K>
+struct Weights {
+    float w[K];
+};
+
+__device__ __forceinline__ float dpp_from_left(float v)
+{
+    // lane l <- lane l-1 (lane 0 gets 0: it is a halo lane, its result is never stored)
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float dpp_from_right(float v)
+{
+    // lane l <- lane l+1 (lane 63 gets 0: never an output lane)
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float ubyte_f32(uint32_t p, int c)
+{
+    return (float)((p >> (8 * c)) & 0xFFu);  // v_cvt_f32_ubyte{c}
+}
+
+// float (>= 0, NaN-free) -> u8 with truncation and an upper clamp, as uchar(std::clamp(v, 0, 255))
+__device__ __forceinline__ uint32_t pack_px(float a, float b, float c, float d)
+{
+    const uint32_t ua = (uint32_t)fminf(a, 255.0f), ub = (uint32_t)fminf(b, 255.0f);
+    const uint32_t uc = (uint32_t)fminf(c, 255.0f), ud = (uint32_t)fminf(d, 255.0f);
+    return ua | (ub << 8) | (uc << 16) | (ud << 24);
+}
+
+template <int R>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
+    int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks, Weights<2 * R + 1> wts)
+{
+    constexpr int K = 2 * R + 1;
+    const int lane = threadIdx.x & 63;
+    const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
+    // everything derived from `work` is wave-uniform: keep it in SGPRs
+    const uint32_t work =
+        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
+    if (work >= nwork)
+        return;
+    const int strip = work % nstrips;
+    const int band = (work / nstrips) % nbands;
+    const size_t frame = work / ((uint32_t)nstrips * nbands);
+
+    const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
+    const int q_load = clampi(q_lane, 0, quads - 1);   // replicated at the image border
+    const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
+    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    const int q_end = min((strip + 1) * lanes_out, quads);
+    const bool stores = (lane >= 1) && (q_lane < q_end);
+
+    const int y0 = band * band_rows;
+    const int nout = min(band_rows, h - y0);
+    const int nin = nout + 2 * R;
+
+    const size_t row_bytes = (size_t)quads * 16;
+    const uint8_t* fin = in + frame * row_bytes * h;    // uniform base; lanes add a 32-bit offset
+    uint8_t* fout = out + frame * row_bytes * h;
+    const uint32_t in_off = (uint32_t)q_load * 16u;
+    const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 16u;
+
+    // weights live in VGPRs: the DPP forms (v_mul_f32_dpp / v_fmac_f32_dpp) take no SGPR operand
+    float wv[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        wv[j] = wts.w[j];
+        asm volatile("" : "+v"(wv[j]));
+    }
+
+    auto load_row = [&](int i) -> u32x4 {
+        // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
+        const int y = clampi(y0 - R + min(i, nin - 1), 0, h - 1);
+        const uint8_t* rowp = fin + (size_t)y * row_bytes;
+        return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rowp + in_off));
+    };
+
+    u32x4 q[K];
+#pragma unroll
+    for (int u = 0; u < K; u++)
+        q[u] = load_row(u);
+
+    float acc[K][16] = {};
+
+    // One trip = K input rows; input row i is tap j of output row m = i - j (m in slot m % K).  The
+    // first 2R rows of a band and the rows of a last partial trip run the same code with their
+    // store masked off: no control flow inside the trip except the store predicate.
+    for (int base = 0; base < nin; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int i = base + u;
+            u32x4 p = q[u];
+            q[u] = load_row(i + K);
+            if (edge_strip) {
+                // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
+                if (left_of_image)
+                    p = u32x4{p.x, p.x, p.x, p.x};
+                if (right_of_image)
+                    p = u32x4{p.w, p.w, p.w, p.w};
+            }
+            float f[16];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                f[0 + c] = ubyte_f32(p.x, c);
+                f[4 + c] = ubyte_f32(p.y, c);
+                f[8 + c] = ubyte_f32(p.z, c);
+                f[12 + c] = ubyte_f32(p.w, c);
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int s = (u - j + K) % K;
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    acc[s][e] = (j == 0) ? wv[0] * f[e] : __builtin_fmaf(wv[j], f[e], acc[s][e]);
+            }
+            const int m = i - 2 * R;  // output row that just received its last tap
+            const float* v = acc[(u + 1) % K];
+            u32x4 o;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float r4[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < K; t++) {
+                        const int s = px - R + t;
+                        float src;
+                        if (s < 0)
+                            src = dpp_from_left(v[(4 + s) * 4 + c]);
+                        else if (s > 3)
+                            src = dpp_from_right(v[(s - 4) * 4 + c]);
+                        else
+                            src = v[s * 4 + c];
+                        sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                    }
+                    r4[c] = sum;
+                }
+                o[px] = pack_px(r4[0], r4[1], r4[2], r4[3]);
+            }
+            if (stores && m >= 0 && m < nout) {
+                uint8_t* rowp = fout + (size_t)(y0 + m) * row_bytes;
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + out_off));
+            }
+        }
+    }
+}
+
+template <int R>
+hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                    const GaussCoef& coef)
+{
+    constexpr int K = 2 * R + 1;
+    const int quads = w / 4;
+    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
+    const int lanes_out = (quads + nstrips - 1) / nstrips;
+    // bands: ~128 rows amortise the 2R warm-up rows to a few percent while leaving >> 256 CUs x 12
+    // waves of work for a batch of 4K frames
+    int band_rows = 128;
+    if (h < band_rows)
+        band_rows = h;
+    const int nbands = (h + band_rows - 1) / band_rows;
+    band_rows = (h + nbands - 1) / nbands;  // balance the bands
+    const size_t nwork = (size_t)nstrips * nbands * nframes;
+    const size_t nblocks = (nwork + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (nblocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    Weights<K> wts;
+    for (int j = 0; j < K; j++)
+        wts.w[j] = coef.h_w1d[j];
+    hipLaunchKernelGGL(gauss_slide_kernel<R>, dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0, stream,
+                       d_in, d_out, quads, h,
+                       nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork, (uint32_t)nblocks, wts);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k)
+{
+    (void)h;
+    if (k != 3 && k != 5 && k != 7 && k != 9)
+        return false;
+    if ((w & 3) != 0)
+        return false;
+    return ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+}
+
+hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                              int nframes, const GaussCoef& coef)
+{
+    switch (coef.k) {
+    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef);
+    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef);
+    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef);
+    case 9: return launch_r<4>(stream, d_in, d_out, w, h, nframes, coef);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mi355

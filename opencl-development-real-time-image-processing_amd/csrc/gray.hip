@@ -1,0 +1,132 @@
+// gray.hip — luminance of RGBA8 frames on gfx950.
+//
+// Replaces kernel `grayscale` (RT/kernel/grayscale_base.cl:1-19) + the host pass
+// Controller::ConvertToUChar (RT/src/Controller.cpp:76-85): u8 in, u8 out, no float4 round trip
+// (the reference writes 16 B/px and converts on one host thread).  Gray value = the CPU path's
+// double-precision formula (src/Grayscale/grayscale.cpp:237), bit-exact.
+//
+// Pure streaming: 4 px (16 B) per lane per access, 4 independent accesses in flight per lane,
+// grid-stride over the flat pixel array (frames are tightly packed, so a batch is one array).
+// Algorithmic bytes: 8 B/px (RGBA out) or 5 B/px (1-channel out).  Bound: HBM.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kGrayThreads = 256;
+constexpr int kGrayIlp = 4;
+
+__device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    return a | (b << 8) | (c << 16) | (d << 24);
+}
+
+template <bool ONE_CH>
+__global__ __launch_bounds__(kGrayThreads) void gray_vec_kernel(const u32x4* __restrict__ in,
+                                                                void* __restrict__ out,
+                                                                size_t nquads)
+{
+    const size_t stride = (size_t)gridDim.x * kGrayThreads;
+    size_t i = (size_t)blockIdx.x * kGrayThreads + threadIdx.x;
+    for (; i + (kGrayIlp - 1) * stride < nquads; i += kGrayIlp * stride) {
+        u32x4 p[kGrayIlp];
+#pragma unroll
+        for (int u = 0; u < kGrayIlp; u++)
+            p[u] = __builtin_nontemporal_load(&in[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < kGrayIlp; u++) {
+            const uint32_t g0 = luma_px(p[u].x), g1 = luma_px(p[u].y);
+            const uint32_t g2 = luma_px(p[u].z), g3 = luma_px(p[u].w);
+            if constexpr (ONE_CH) {
+                __builtin_nontemporal_store(pack4(g0, g1, g2, g3),
+                                            &reinterpret_cast<uint32_t*>(out)[i + u * stride]);
+            } else {
+                u32x4 o;
+                o.x = gray_to_rgba(g0);
+                o.y = gray_to_rgba(g1);
+                o.z = gray_to_rgba(g2);
+                o.w = gray_to_rgba(g3);
+                __builtin_nontemporal_store(o, &reinterpret_cast<u32x4*>(out)[i + u * stride]);
+            }
+        }
+    }
+    for (; i < nquads; i += stride) {
+        const u32x4 p = in[i];
+        const uint32_t g0 = luma_px(p.x), g1 = luma_px(p.y), g2 = luma_px(p.z), g3 = luma_px(p.w);
+        if constexpr (ONE_CH) {
+            reinterpret_cast<uint32_t*>(out)[i] = pack4(g0, g1, g2, g3);
+        } else {
+            u32x4 o;
+            o.x = gray_to_rgba(g0);
+            o.y = gray_to_rgba(g1);
+            o.z = gray_to_rgba(g2);
+            o.w = gray_to_rgba(g3);
+            reinterpret_cast<u32x4*>(out)[i] = o;
+        }
+    }
+}
+
+// one pixel per thread: tails and buffers that are not 16-byte aligned
+template <bool ONE_CH>
+__global__ __launch_bounds__(kGrayThreads) void gray_px_kernel(const uint8_t* __restrict__ in,
+                                                               uint8_t* __restrict__ out,
+                                                               size_t first, size_t npx)
+{
+    const size_t stride = (size_t)gridDim.x * kGrayThreads;
+    for (size_t i = first + (size_t)blockIdx.x * kGrayThreads + threadIdx.x; i < npx; i += stride) {
+        const uint32_t g = luma_rgb(in[4 * i], in[4 * i + 1], in[4 * i + 2]);
+        if constexpr (ONE_CH) {
+            out[i] = (uint8_t)g;
+        } else {
+            out[4 * i] = (uint8_t)g;
+            out[4 * i + 1] = (uint8_t)g;
+            out[4 * i + 2] = (uint8_t)g;
+            out[4 * i + 3] = 255;
+        }
+    }
+}
+
+inline unsigned grid_for(size_t items, unsigned per_block, unsigned cap)
+{
+    size_t b = (items + per_block - 1) / per_block;
+    if (b < 1)
+        b = 1;
+    return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                       int nframes, bool one_channel)
+{
+    const size_t npx = (size_t)w * h * nframes;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(d_out) & (one_channel ? 3u : 15u)) == 0);
+    const size_t nquads = aligned ? npx / 4 : 0;
+    // 256 CUs x 8 resident blocks; grid-stride the rest (guide: cap ~2048 blocks for streaming)
+    constexpr unsigned kCap = 256 * 8;
+    if (nquads) {
+        const unsigned grid = grid_for(nquads, kGrayThreads * kGrayIlp, kCap);
+        if (one_channel)
+            hipLaunchKernelGGL(gray_vec_kernel<true>, dim3(grid), dim3(kGrayThreads), 0, stream,
+                               reinterpret_cast<const u32x4*>(d_in), (void*)d_out, nquads);
+        else
+            hipLaunchKernelGGL(gray_vec_kernel<false>, dim3(grid), dim3(kGrayThreads), 0, stream,
+                               reinterpret_cast<const u32x4*>(d_in), (void*)d_out, nquads);
+    }
+    const size_t done = nquads * 4;
+    if (done < npx) {
+        const unsigned grid = grid_for(npx - done, kGrayThreads, kCap);
+        if (one_channel)
+            hipLaunchKernelGGL(gray_px_kernel<true>, dim3(grid), dim3(kGrayThreads), 0, stream, d_in,
+                               d_out, done, npx);
+        else
+            hipLaunchKernelGGL(gray_px_kernel<false>, dim3(grid), dim3(kGrayThreads), 0, stream, d_in,
+                               d_out, done, npx);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mi355

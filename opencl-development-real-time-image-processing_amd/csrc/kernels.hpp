@@ -1,0 +1,49 @@
+// kernels.hpp — host-callable launchers of the gfx950 kernels (one .hip file each).
+// All launchers enqueue on `stream` and return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+// Coefficients of one (k, sigma), device-resident, owned by the context.
+//   w2d : k*k floats, the reference's table (RT/src/Controller.cpp:352-372), row-major.
+//   w1d : k floats, the separable factor used by the FAST arithmetic:
+//         w1d[i] = rowsum_i(w2d) / sqrt(sum(w2d)) evaluated in double, rounded to float.
+struct GaussCoef {
+    int k;
+    const float* d_w2d;
+    const float* d_w1d;
+    float h_w1d[64];  // host copy, passed by value to the register-resident kernels
+};
+
+hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                       int nframes, bool one_channel);
+
+// impl: 0 = choose (sliding window when supported), 1 = force the LDS-tiled kernel
+hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                        int nframes, const GaussCoef& coef, bool exact, int impl);
+
+// the two implementations launch_gauss chooses between
+hipError_t launch_gauss_tile(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                             int nframes, const GaussCoef& coef, bool exact);
+
+// register-resident sliding-window kernel (k = 3,5,7,9; width % 4 == 0; 16-byte aligned buffers)
+bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                              int nframes, const GaussCoef& coef);
+
+hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                        int nframes);
+
+hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
+                           int nframes, const GaussCoef& coef, bool exact);
+
+hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nframes,
+                        int first_frame, uint32_t seed, int mode);
+
+// *d_acc += order-independent checksum of nbytes at d_buf (see include/mi355_imgfilter.h)
+hipError_t launch_checksum(hipStream_t stream, const uint8_t* d_buf, size_t nbytes,
+                           uint64_t index_base, unsigned long long* d_acc);
+
+}  // namespace mi355

@@ -1,0 +1,108 @@
+// util.hip — synthetic-frame generator and the order-independent checksum (measurement and
+// multi-GPU parity helpers; SURVEY.md §8d "Config 2-5", "Parity sampling").
+// Both are defined bit-for-bit by their CPU twins in oracle/imgfilter_oracle.c.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ uint32_t synth_hash(uint32_t seed, uint32_t frame, uint32_t y, uint32_t x)
+{
+    uint32_t hsh = seed ^ (frame * 0x9E3779B1u);
+    hsh = fmix32(hsh ^ (y * 0x85EBCA77u));
+    hsh = fmix32(hsh ^ (x * 0xC2B2AE3Du));
+    return hsh;
+}
+
+__global__ __launch_bounds__(kThreads) void synth_kernel(uint32_t* __restrict__ out, int w, int h,
+                                                         int nframes, int first_frame, uint32_t seed,
+                                                         int mode)
+{
+    const size_t npx = (size_t)w * h * nframes;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    const size_t per_frame = (size_t)w * h;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < npx; i += stride) {
+        const uint32_t f = (uint32_t)(i / per_frame);
+        const uint32_t rem = (uint32_t)(i - (size_t)f * per_frame);
+        const uint32_t y = rem / (uint32_t)w, x = rem - y * (uint32_t)w;
+        const uint32_t hsh = synth_hash(seed, (uint32_t)first_frame + f, y, x);
+        uint32_t px;
+        if (mode == 0) {
+            px = (hsh & 0x00FFFFFFu) | 0xFF000000u;
+        } else {
+            const int gx = (int)((x * 255u) / (uint32_t)(w > 1 ? w - 1 : 1));
+            const int gy = (int)((y * 255u) / (uint32_t)(h > 1 ? h - 1 : 1));
+            const int r = clampi(gx + (int)(hsh & 15u) - 8, 0, 255);
+            const int g = clampi(gy + (int)((hsh >> 8) & 15u) - 8, 0, 255);
+            const int b = clampi(((gx + gy) >> 1) + (int)((hsh >> 16) & 15u) - 8, 0, 255);
+            px = (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xFF000000u;
+        }
+        out[i] = px;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void checksum_kernel(const uint8_t* __restrict__ buf,
+                                                            size_t nbytes, uint64_t index_base,
+                                                            unsigned long long* __restrict__ acc)
+{
+    const size_t nwords = nbytes >> 2;
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    uint64_t sum = 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(buf) & 3u) == 0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nwords; i += stride) {
+        uint32_t wv;
+        if (aligned)
+            wv = reinterpret_cast<const uint32_t*>(buf)[i];
+        else
+            wv = (uint32_t)buf[4 * i] | ((uint32_t)buf[4 * i + 1] << 8) |
+                 ((uint32_t)buf[4 * i + 2] << 16) | ((uint32_t)buf[4 * i + 3] << 24);
+        sum += fmix64((uint64_t)wv + ((index_base + i) << 32));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (nbytes & 3u)) {
+        uint32_t wv = 0;
+        for (size_t b = 0; b < (nbytes & 3u); b++)
+            wv |= (uint32_t)buf[4 * nwords + b] << (8 * b);
+        sum += fmix64((uint64_t)wv + ((index_base + nwords) << 32));
+    }
+    // wave reduction, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        atomicAdd(acc, (unsigned long long)sum);
+}
+
+}  // namespace
+
+hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nframes, int first_frame,
+                        uint32_t seed, int mode)
+{
+    const size_t npx = (size_t)w * h * nframes;
+    size_t blocks = (npx + kThreads - 1) / kThreads;
+    if (blocks > 256 * 8)
+        blocks = 256 * 8;
+    if (blocks < 1)
+        blocks = 1;
+    hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                       reinterpret_cast<uint32_t*>(d_out), w, h, nframes, first_frame, seed, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_checksum(hipStream_t stream, const uint8_t* d_buf, size_t nbytes, uint64_t index_base,
+                           unsigned long long* d_acc)
+{
+    size_t blocks = ((nbytes >> 2) + kThreads - 1) / kThreads;
+    if (blocks > 256 * 8)
+        blocks = 256 * 8;
+    if (blocks < 1)
+        blocks = 1;
+    hipLaunchKernelGGL(checksum_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_buf, nbytes,
+                       index_base, d_acc);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

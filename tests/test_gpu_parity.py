@@ -1,0 +1,258 @@
+"""GPU suite (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same seeded
+inputs.  Bars: bit-exact for grayscale, Sobel, the EXACT Gaussian and the EXACT pipeline; |d| <= 1 LSB
+per channel for the FAST (separable, FMA) Gaussian — the tolerance BASELINE.json's north_star states."""
+import numpy as np
+import pytest
+
+from conftest import rand_rgba
+
+pytestmark = pytest.mark.gpu
+
+# the reference's own image sizes (images/*.jpg: 75x75, 240x?, 640x512, 1023x819 — widths that are not
+# multiples of 4 or 64) plus degenerate and tile-boundary shapes.  (h, w)
+SIZES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (16, 64), (17, 65), (75, 75), (33, 248), (40, 252),
+         (31, 256), (64, 500), (130, 1023)]
+
+
+def test_context_reports_gfx950(ctx):
+    assert "gfx950" in ctx.device_name
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_gray_bit_exact(ctx, oracle, h, w):
+    img = rand_rgba(h, w, seed=h * 1000 + w, alpha=None)
+    assert np.array_equal(ctx.gray(img), oracle.gray_rgba(img))
+    assert np.array_equal(ctx.gray1(img), oracle.gray_rgba_1ch(img))
+
+
+def test_gray_all_16m_colours(ctx, oracle):
+    r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    rgba = np.stack([r, g, b, np.full_like(r, 255)], -1).astype(np.uint8).reshape(4096, 4096, 4)
+    got = ctx.gray1(rgba)
+    assert np.array_equal(got, oracle.gray_rgba_1ch(rgba))
+    assert got.reshape(256, 256, 256)[0, 72, 24] == 44
+
+
+def test_gray_fixture_config1(ctx, oracle, fixture_rgba):
+    assert np.array_equal(ctx.gray1(fixture_rgba), oracle.gray_rgba_1ch(fixture_rgba))
+
+
+def _gauss_check(ctx, pkg, oracle, img, k, sigma):
+    ref = oracle.gauss_rgba(img, k, sigma)
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    exact = ctx.gauss(img, k, sigma)
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    fast = ctx.gauss(img, k, sigma)
+    assert np.array_equal(exact, ref), "EXACT mode must be bit-identical to the CPU path"
+    d = np.abs(fast.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1, "FAST mode tolerance is 1 LSB per channel (north_star)"
+    return float((d != 0).mean())
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_gauss_5x5(ctx, pkg, oracle, h, w):
+    img = rand_rgba(h, w, seed=h * 77 + w, alpha=None)
+    frac = _gauss_check(ctx, pkg, oracle, img, 5, 1.5)
+    if img.size >= 4096:  # a rate is meaningless on a handful of values
+        assert frac < 0.01   # off-by-one only where the sum sits within float rounding of an integer
+
+
+@pytest.mark.parametrize("k,sigma", [(1, 1.0), (3, 0.8), (7, 2.0), (9, 2.5), (17, 6.0), (31, 10.0)])
+def test_gauss_other_kernels(ctx, pkg, oracle, k, sigma):
+    img = rand_rgba(45, 83, seed=k, alpha=None)
+    _gauss_check(ctx, pkg, oracle, img, k, sigma)
+
+
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0), (9, 2.5)])
+@pytest.mark.parametrize("h,w", [(1, 4), (3, 8), (40, 252), (33, 248), (7, 256), (131, 500), (300, 1920), (5, 3840)])
+def test_gauss_sliding_window_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, sigma, h, w):
+    """The register-resident kernel (gauss_slide.hip; width % 4 == 0, k <= 9) and the LDS-tiled kernel
+    implement one canonical FAST arithmetic: identical bits.  Both are within 1 LSB of the CPU path."""
+    img = rand_rgba(h, w, seed=h * 7 + w + k, alpha=None)
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    tiled = ctx.gauss(img, k, sigma)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    slide = ctx.gauss(img, k, sigma)
+    assert np.array_equal(slide, tiled)
+    ref = oracle.gauss_rgba(img, k, sigma)
+    assert np.abs(slide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+
+
+def test_gauss_sliding_window_batched_multi_band(ctx, pkg, oracle):
+    """Several frames, several bands per frame (h > 128), several strips (w > 248), edge strips."""
+    frames = oracle.synth_rgba(1000, 300, 3, first_frame=1, mode=1)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    tiled = ctx.gauss(frames, 5, 1.5)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    slide = ctx.gauss(frames, 5, 1.5)
+    assert np.array_equal(slide, tiled)
+    ref = oracle.gauss_rgba(frames[2], 5, 1.5)
+    d = np.abs(slide[2].astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 0.01
+
+
+def test_gauss_known_answers(ctx, pkg):
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    assert np.unique(ctx.gauss(np.full((40, 70, 4), 255, np.uint8), 5, 1.5)).tolist() == [254]
+    assert np.unique(ctx.gauss(np.full((40, 70, 4), 200, np.uint8), 5, 1.5)).tolist() == [200]
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    assert set(np.unique(ctx.gauss(np.full((40, 70, 4), 255, np.uint8), 5, 1.5)).tolist()) <= {254, 255}
+
+
+def test_gauss_photographic_fixture(ctx, pkg, oracle, fixture_rgba):
+    frac = _gauss_check(ctx, pkg, oracle, fixture_rgba, 5, 1.5)
+    assert frac < 0.01
+
+
+def test_gauss_external_weight_table(ctx, pkg, oracle):
+    """Multi-GPU mode installs a broadcast table instead of generating it."""
+    img = rand_rgba(30, 50, seed=9)
+    table = oracle.gauss_weights(5, 1.5)
+    ctx.set_gauss_weights(5, 1.5, table)
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    assert np.array_equal(ctx.gauss(img, 5, 1.5), oracle.gauss_rgba(img, 5, weights=table))
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_sobel_bit_exact(ctx, oracle, h, w):
+    img = rand_rgba(h, w, seed=h * 31 + w)
+    assert np.array_equal(ctx.sobel(img), oracle.sobel_rgba(img))
+
+
+def test_sobel_known_answers(ctx):
+    flat = np.full((20, 70, 4), 90, np.uint8)
+    assert ctx.sobel(flat).max() == 0
+    step = np.zeros((20, 70, 4), np.uint8)
+    step[:, 35:, :3] = 255
+    out = ctx.sobel(step)
+    assert (out[:, [34, 35]] == 255).all() and out[:, :34].max() == 0 and out[:, 36:].max() == 0
+
+
+def test_sobel_smooth_frames(ctx, oracle):
+    img = oracle.synth_rgba(333, 97, 1, mode=1)[0]
+    assert np.array_equal(ctx.sobel(img), oracle.sobel_rgba(img))
+
+
+@pytest.mark.parametrize("h,w", SIZES)
+def test_pipeline(ctx, pkg, oracle, h, w):
+    img = rand_rgba(h, w, seed=h * 13 + w)
+    k, sigma = 5, 1.5
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    assert np.array_equal(ctx.pipeline(img, k, sigma), oracle.pipeline_rgba(img, k, sigma))
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    fused = ctx.pipeline(img, k, sigma)
+    chained = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
+    assert np.array_equal(fused, chained), "fused kernel == the three API calls chained"
+
+
+def test_pipeline_other_kernels(ctx, pkg, oracle):
+    img = oracle.synth_rgba(150, 70, 1, mode=1)[0]
+    for k, sigma in ((3, 0.8), (9, 2.5), (17, 6.0)):
+        ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+        assert np.array_equal(ctx.pipeline(img, k, sigma), oracle.pipeline_rgba(img, k, sigma))
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        assert np.array_equal(ctx.pipeline(img, k, sigma), ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma)))
+
+
+def test_batched_equals_per_frame(ctx, oracle):
+    frames = oracle.synth_rgba(120, 45, 5, first_frame=2)
+    for name in ("gray", "sobel"):
+        batched = getattr(ctx, name)(frames)
+        for f in range(5):
+            assert np.array_equal(batched[f], getattr(ctx, name)(frames[f]))
+    g = ctx.gauss(frames, 5, 1.5)
+    p = ctx.pipeline(frames, 5, 1.5)
+    for f in range(5):
+        assert np.array_equal(g[f], ctx.gauss(frames[f], 5, 1.5))
+        assert np.array_equal(p[f], ctx.pipeline(frames[f], 5, 1.5))
+
+
+def test_per_frame_entry_points_and_profiling_contract(ctx, oracle):
+    """mi355_*_rgba8: six timestamps, write/kernel/read, non-decreasing (Controller.cpp:66-74)."""
+    img = rand_rgba(64, 96, seed=4)
+    out, prof = ctx.single("gray", img)
+    assert np.array_equal(out, oracle.gray_rgba(img))
+    assert len(prof) == 6 and all(b >= a for a, b in zip(prof, prof[1:])) and prof[5] > prof[0]
+    out, prof = ctx.single("sobel", img)
+    assert np.array_equal(out, oracle.sobel_rgba(img))
+    out, prof = ctx.single("gauss", img, 5, 1.5)
+    assert np.abs(out.astype(int) - oracle.gauss_rgba(img, 5, 1.5).astype(int)).max() <= 1
+    out, _ = ctx.single("gray1", img)
+    assert np.array_equal(out, oracle.gray_rgba_1ch(img))
+
+
+def test_synth_and_checksum_match_cpu_twins(ctx, oracle):
+    w, h, n = 251, 67, 3
+    for mode in (0, 1):
+        d = ctx.alloc(w * h * n * 4)
+        ctx.synth_dev(d, w, h, n, first_frame=3, seed=0x5EED, mode=mode)
+        got = np.empty((n, h, w, 4), np.uint8)
+        ctx.d2h(got, d)
+        ref = oracle.synth_rgba(w, h, n, first_frame=3, seed=0x5EED, mode=mode)
+        assert np.array_equal(got, ref)
+        assert ctx.checksum_dev(d, got.nbytes) == oracle.checksum(ref)
+        per = w * h
+        parts = sum(ctx.checksum_dev(d + f * per * 4, per * 4, index_base=f * per) for f in range(n))
+        assert parts % (1 << 64) == oracle.checksum(ref)
+        ctx.free(d)
+
+
+def test_device_resident_api(ctx, pkg, oracle):
+    w, h, n = 256, 40, 3
+    frames = oracle.synth_rgba(w, h, n)
+    d_in = ctx.alloc(frames.nbytes)
+    d_out = ctx.alloc(frames.nbytes)
+    ctx.h2d(d_in, frames)
+    ctx.filter_dev(pkg.FILTER_SOBEL, d_in, d_out, w, h, n)
+    got = np.empty((n, h, w), np.uint8)
+    ctx.d2h(got, d_out)
+    for f in range(n):
+        assert np.array_equal(got[f], oracle.sobel_rgba(frames[f]))
+    ctx.free(d_in)
+    ctx.free(d_out)
+
+
+def test_bad_arguments_are_rejected_not_launched(ctx, pkg):
+    img = rand_rgba(8, 8, seed=1)
+    for k, sigma in ((4, 1.0), (0, 1.0), (65, 1.0), (5, 0.0), (5, float("inf"))):
+        with pytest.raises(pkg.Mi355Error):
+            ctx.gauss(img, k, sigma)
+    with pytest.raises(pkg.Mi355Error):
+        ctx.filter_dev(pkg.FILTER_GRAY, 0, 0, 8, 8, 1)
+    with pytest.raises(pkg.Mi355Error):
+        ctx.filter_dev(42, 16, 16, 8, 8, 1)
+    assert np.array_equal(ctx.gray(img)[..., 3], np.full((8, 8), 255, np.uint8))   # still usable
+
+
+# ---- BASELINE.json full sizes: size-independent properties ------------------------------------
+def test_full_size_4k_properties(ctx, pkg, oracle):
+    """4K frames: the oracle is too slow for whole frames (Gaussian ~0.3 s/frame/thread), so check
+    (a) a random band of rows against the oracle, computed on a crop with enough margin,
+    (b) fused == chained, (c) constant / translation properties, (d) checksums of a batch."""
+    w, h = 3840, 2160
+    frame = oracle.synth_rgba(w, h, 1, first_frame=7, mode=1)[0]
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    gauss = ctx.gauss(frame, 5, 1.5)
+    sob = ctx.sobel(frame)
+    pipe = ctx.pipeline(frame, 5, 1.5)
+    assert np.array_equal(pipe, ctx.sobel(ctx.gauss(ctx.gray(frame), 5, 1.5)))
+    # (a) rows [y0, y1) of the full-frame result == the oracle on a crop with a 3-row margin
+    for y0, y1 in ((0, 24), (1000, 1024), (2136, 2160)):
+        a, b = max(0, y0 - 3), min(h, y1 + 3)
+        crop = frame[a:b]
+        ref_g = oracle.gauss_rgba(crop, 5, 1.5)[y0 - a:y1 - a]
+        assert np.abs(gauss[y0:y1].astype(int) - ref_g.astype(int)).max() <= 1
+        # Sobel uses reflect-101 at the true image border only: interior rows of the crop are valid
+        ref_s = oracle.sobel_rgba(crop)
+        lo = 0 if a == 0 else 1
+        hi = (b - a) if b == h else (b - a - 1)
+        assert np.array_equal(sob[a + lo:a + hi], ref_s[lo:hi])
+    # (c) a constant frame stays constant; shifting the content shifts the interior of the result
+    const = np.full((h, w, 4), 200, np.uint8)
+    assert np.unique(ctx.gauss(const, 5, 1.5)).tolist() == [200]
+    assert ctx.sobel(const).max() == 0
+    shifted = np.roll(frame, 64, axis=1)
+    g2 = ctx.gauss(shifted, 5, 1.5)
+    assert np.array_equal(g2[:, 64 + 2:-2], gauss[:, 2:-64 - 2])
