@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
     return p.parse_args()
 
 
@@ -146,6 +147,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # on-box streaming ceiling for the same byte count: a device-to-device copy of the input batch
+    # (reads 4 B/px, writes 4 B/px = the Gaussian's algorithmic traffic), timed with the same events
+    copy_gbs = None
+    if rank == 0 and not args.no_ceiling:
+        scratch = torch.empty_like(d_in)
+        for _ in range(2):
+            scratch.copy_(d_in)
+        torch.cuda.synchronize(dev)
+        ctx.timer_begin()
+        for _ in range(5):
+            scratch.copy_(d_in)
+        copy_ms = ctx.timer_end() / 5
+        copy_gbs = 2 * d_in.numel() / (copy_ms * 1e-3) / 1e9
+        del scratch
+        torch.cuda.empty_cache()
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -206,6 +223,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         "copy_ceiling_GBs": copy_gbs,
+                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": avg_launch_ms, "avg_launch_ms_max_over_ranks": ms_max,
                          "kernel": "see profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
             "checksum": "%016x" % ck_sum,

@@ -54,15 +54,22 @@ __device__ __forceinline__ float ubyte_f32(uint32_t p, int c)
     return (float)((p >> (8 * c)) & 0xFFu);  // v_cvt_f32_ubyte{c}
 }
 
-// float (>= 0, NaN-free) -> u8 with truncation and an upper clamp, as uchar(std::clamp(v, 0, 255))
+// float -> u8 as uchar(std::clamp(v, 0.f, 255.f)).  The sums here are >= 0 and NaN-free (non-negative
+// weights times u8), so only the upper clamp can matter, and it cannot when 255 * (sum of weights)^2
+// < 256: the launcher selects CLAMP = false for such tables (every normalised Gaussian).
+template <bool CLAMP>
 __device__ __forceinline__ uint32_t pack_px(float a, float b, float c, float d)
 {
-    const uint32_t ua = (uint32_t)fminf(a, 255.0f), ub = (uint32_t)fminf(b, 255.0f);
-    const uint32_t uc = (uint32_t)fminf(c, 255.0f), ud = (uint32_t)fminf(d, 255.0f);
-    return ua | (ub << 8) | (uc << 16) | (ud << 24);
+    if constexpr (CLAMP) {
+        a = fminf(a, 255.0f);
+        b = fminf(b, 255.0f);
+        c = fminf(c, 255.0f);
+        d = fminf(d, 255.0f);
+    }
+    return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
 }
 
-template <int R>
+template <int R, bool CLAMP>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
     int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks, Weights<2 * R + 1> wts)
@@ -108,7 +115,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
         const int y = clampi(y0 - R + min(i, nin - 1), 0, h - 1);
         const uint8_t* rowp = fin + (size_t)y * row_bytes;
-        return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(rowp + in_off));
+        // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
+        return *reinterpret_cast<const u32x4*>(rowp + in_off);
     };
 
     u32x4 q[K];
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
                     }
                     r4[c] = sum;
                 }
-                o[px] = pack_px(r4[0], r4[1], r4[2], r4[3]);
+                o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
             }
             if (stores && m >= 0 && m < nout) {
                 uint8_t* rowp = fout + (size_t)(y0 + m) * row_bytes;
@@ -204,9 +212,18 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     Weights<K> wts;
     for (int j = 0; j < K; j++)
         wts.w[j] = coef.h_w1d[j];
-    hipLaunchKernelGGL(gauss_slide_kernel<R>, dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0, stream,
-                       d_in, d_out, quads, h,
-                       nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork, (uint32_t)nblocks, wts);
+    double wsum = 0.0;
+    for (int j = 0; j < K; j++)
+        wsum += (double)coef.h_w1d[j];
+    const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);  // externally installed tables may overflow
+    if (clamp)
+        hipLaunchKernelGGL((gauss_slide_kernel<R, true>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands,
+                           (uint32_t)nwork, (uint32_t)nblocks, wts);
+    else
+        hipLaunchKernelGGL((gauss_slide_kernel<R, false>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands,
+                           (uint32_t)nwork, (uint32_t)nblocks, wts);
     return hipGetLastError();
 }
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs written by tools/prof.sh into one text summary:
+per-kernel count / average duration from the kernel trace, and per-kernel counter sums per dispatch."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("== kernel trace (per kernel: dispatches, avg / min / max duration in us) ==")
+for f in find("trace/**/*kernel_trace.csv"):
+    rows = list(csv.DictReader(open(f)))
+    agg = defaultdict(list)
+    for r in rows:
+        agg[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        print("%-90s n=%4d avg=%10.2f min=%10.2f max=%10.2f" % (k[:90], len(v), sum(v) / len(v), min(v), max(v)))
+    for r in rows[:1]:
+        print("columns:", ",".join(r.keys()))
+    regs = {}
+    for r in rows:
+        regs[r["Kernel_Name"]] = (r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
+                                  r.get("Workgroup_Size"), r.get("Grid_Size"))
+    for k, v in regs.items():
+        print("  %-80s vgpr=%s sgpr=%s lds=%s wg=%s grid=%s" % (k[:80], *v))
+for f in find("trace/**/*kernel_stats.csv"):
+    print("== kernel stats ==")
+    print(open(f).read())
+
+print("== PMC (per kernel: mean counter value per dispatch) ==")
+for f in find("pmc*/**/*counter_collection.csv"):
+    rows = list(csv.DictReader(open(f)))
+    agg = defaultdict(lambda: defaultdict(list))
+    for r in rows:
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in agg.items():
+        if "gauss" in k or "sobel" in k or "gray" in k or "pipeline" in k:
+            for c, v in cs.items():
+                print("%-60s %-24s n=%3d mean=%.6g" % (k[:60], c, len(v), sum(v) / len(v)))
