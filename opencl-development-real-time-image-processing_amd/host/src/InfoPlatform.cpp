@@ -1,0 +1,45 @@
+// InfoPlatform.cpp — prints the four platform strings (reference: RT/src/InfoPlatform.cpp:3-25).
+#include "InfoPlatform.hpp"
+
+static std::string query(cl_platform_id id, cl_platform_info name)
+{
+    size_t n = 0;
+    if (clGetPlatformInfo(id, name, 0, nullptr, &n) != CL_SUCCESS || n == 0)
+        return {};
+    std::string s(n, '\0');
+    if (clGetPlatformInfo(id, name, n, s.data(), nullptr) != CL_SUCCESS)
+        return {};
+    s.resize(n - 1);
+    return s;
+}
+
+InfoPlatform::InfoPlatform(cl_platform_id id)
+    : m_profile(query(id, CL_PLATFORM_PROFILE)), m_name(query(id, CL_PLATFORM_NAME)),
+      m_version(query(id, CL_PLATFORM_VERSION)), m_vendor(query(id, CL_PLATFORM_VENDOR))
+{
+}
+
+void InfoPlatform::DisplaySinglePlatformInfo(cl_platform_id id, cl_platform_info name, std::string str)
+{
+    std::cout << "\t" << str << "\t" << query(id, name) << std::endl;
+}
+
+void InfoPlatform::Display()
+{
+    std::cout << "\nPLATFORM PROPERTIES:" << std::endl;
+    std::cout << "\tCL_PLATFORM_PROFILE\t" << m_profile << std::endl;
+    std::cout << "\tCL_PLATFORM_NAME\t" << m_name << std::endl;
+    std::cout << "\tCL_PLATFORM_VERSION\t" << m_version << std::endl;
+    std::cout << "\tCL_PLATFORM_VENDOR\t" << m_vendor << std::endl;
+}
+
+std::string InfoPlatform::GetPlatformInfo(cl_platform_info name)
+{
+    switch (name) {
+    case CL_PLATFORM_PROFILE: return m_profile;
+    case CL_PLATFORM_NAME: return m_name;
+    case CL_PLATFORM_VERSION: return m_version;
+    case CL_PLATFORM_VENDOR: return m_vendor;
+    default: std::cerr << "Unrecognised platform info" << std::endl; return {};
+    }
+}

@@ -1,0 +1,285 @@
+// ProgramHandler.cpp — the reference's ProgramHandler (RT/src/ProgramHandler.cpp:1-329) over the new
+// Controller: flag holder, InitOpenCL (method -> kernel name, image-support probe / bypass -> kernel file),
+// the N-iteration timed loop of PerformOpenCL(image_path, ...) and the one-frame PerformOpenCL(cv::Mat, ...).
+// Differences, all deliberate:
+//   * the timed loop reads the profiling events of the CURRENT iteration; the reference indexes [0..5] of a
+//     vector it never clears (:219-221), so its published kernel/write/read averages repeat iteration 0;
+//   * without OpenCV (this container) image files are read as binary PPM (P6) instead of cv::imread.
+#include "ProgramHandler.hpp"
+
+#include <cassert>
+#include <chrono>
+#include <cstdlib>
+#include <fstream>
+
+ProgramHandler::ProgramHandler(int number_of_iterations, bool log_events, bool display_images,
+                               bool display_terminal_results, bool bypass_image_support, int gaussian_kernel_size,
+                               float gaussian_sigma)
+    : LOG_EVENTS{log_events}, DISPLAY_IMAGES{display_images}, DISPLAY_TERMINAL_RESULTS{display_terminal_results},
+      BYPASS_IMAGE_SUPPORT{bypass_image_support}, NUMBER_OF_ITERATIONS{number_of_iterations}, PLATFORM_INDEX{0},
+      DEVICE_INDEX{0}, GAUSSIAN_KERNEL_SIZE{gaussian_kernel_size}, GAUSSIAN_SIGMA{gaussian_sigma}
+{
+    METHOD = {"GRAYSCALE", "GAUSSIAN"};
+}
+
+void ProgramHandler::InitLogger(Logger& logger, Logger::LogLevel level, bool save_to_file)
+{
+    try {
+        logger.setLogFile("RealtimeImageProcessing.log", save_to_file);
+        logger.setLogLevel(level);
+        logger.setTerminalDisplay(DISPLAY_TERMINAL_RESULTS);
+        logger.log("Initialised logger", Logger::LogLevel::INFO);
+    } catch (const std::exception& e) {
+        std::cerr << "Error setting log file: " << e.what() << std::endl;
+    }
+}
+
+void ProgramHandler::AddKernels(std::vector<std::string> kernels, std::string kernel_index)
+{
+    KERNELS.insert({kernel_index, kernels});
+}
+
+void ProgramHandler::SetDeviceProperties(int platform_index, int device_index)
+{
+    PLATFORM_INDEX = platform_index;
+    DEVICE_INDEX = device_index;
+}
+
+void ProgramHandler::InitOpenCL(Controller& controller, cl_context* context, cl_command_queue* command_queue,
+                                cl_program* program, cl_kernel* kernel, std::string method, Logger& logger)
+{
+    auto platforms = controller.GetPlatforms();
+    if (PLATFORM_INDEX < 0 || PLATFORM_INDEX >= (int)platforms.size())
+        controller.CheckError(CL_INVALID_VALUE, "clGetPlatformIDs");
+    auto devices = controller.GetDevices(platforms[PLATFORM_INDEX]);
+    if (DEVICE_INDEX < 0 || DEVICE_INDEX >= (int)devices.size())
+        controller.CheckError(CL_INVALID_DEVICE, "clGetDeviceIDs");
+
+    if (DISPLAY_TERMINAL_RESULTS) {
+        for (auto&& platform : platforms)
+            controller.DisplayPlatformInformation(platform);
+        std::ostringstream oss;
+        oss << "\nApplication will use:\nPLATFORM INDEX:\t" << PLATFORM_INDEX << "\nDEVICE INDEX:\t" << DEVICE_INDEX
+            << "\n"
+            << std::endl;
+        logger.log(oss.str(), Logger::LogLevel::INFO);
+        oss.str("");
+        char device_name[256] = {};
+        clGetDeviceInfo(devices[DEVICE_INDEX], CL_DEVICE_NAME, sizeof(device_name), device_name, NULL);
+        oss << "Device name: " << device_name << std::endl;
+        logger.log(oss.str(), Logger::LogLevel::INFO);
+    }
+
+    std::string kernel_name;
+    if (method == "GRAYSCALE") {
+        kernel_name = "grayscale";
+    } else if (method == "EDGE") {
+        kernel_name = "sobel_edge_detection";
+    } else if (method == "GAUSSIAN") {
+        kernel_name = "gaussian_blur";
+    } else {
+        std::cerr << "Unrecognised method" << std::endl;
+        exit(1);
+    }
+
+    // KERNELS[method] = {image2d file, buffer file}; without an AddKernels entry fall back to the app's
+    // own naming scheme so the family is still recognisable
+    std::vector<std::string> files = KERNELS.count(method) ? KERNELS[method] : std::vector<std::string>{};
+    if (files.size() < 2) {
+        const std::string stem = method == "GRAYSCALE" ? "grayscale" : (method == "EDGE" ? "edge" : "gaussian");
+        files = {stem + "_images.cl", stem + "_base.cl"};
+    }
+    std::string kernel_file;
+    cl_bool image_support = CL_FALSE;
+    if (!BYPASS_IMAGE_SUPPORT) {
+        clGetDeviceInfo(devices[DEVICE_INDEX], CL_DEVICE_IMAGE_SUPPORT, sizeof(cl_bool), &image_support, nullptr);
+        if (image_support == CL_FALSE) {
+            kernel_file = files[1];
+            std::cout << "Device does not support images. Using buffers instead of image2D structures." << std::endl;
+        } else {
+            kernel_file = files[0];
+            std::cout << "Device supports images." << std::endl;
+        }
+    } else {
+        kernel_file = files[1];
+        std::cout << "Bypass image support is True. Using buffers instead of image2D structures." << std::endl;
+    }
+    controller.SetImageSupport(image_support);
+
+    *context = controller.CreateContext(platforms[PLATFORM_INDEX], devices);
+    *command_queue = controller.CreateCommandQueue(*context, devices[DEVICE_INDEX]);
+    *program = controller.CreateProgram(*context, devices[DEVICE_INDEX], kernel_file.c_str());
+    *kernel = controller.CreateKernel(*program, kernel_name.c_str());
+}
+
+#ifdef MI355_NO_OPENCV
+// binary PPM (P6, maxval 255) -> tightly packed RGBA, A = 255
+static bool read_ppm_rgba(const std::string& path, std::vector<unsigned char>* rgba, cl_int* width, cl_int* height)
+{
+    std::ifstream f(path, std::ios::binary);
+    std::string magic;
+    int w = 0, h = 0, maxv = 0;
+    auto next_int = [&](int& v) {
+        std::string tok;
+        while (f >> tok) {
+            if (tok[0] == '#') {
+                std::string rest;
+                std::getline(f, rest);
+                continue;
+            }
+            v = std::atoi(tok.c_str());
+            return true;
+        }
+        return false;
+    };
+    if (!(f >> magic) || magic != "P6" || !next_int(w) || !next_int(h) || !next_int(maxv) || maxv != 255 ||
+        w <= 0 || h <= 0)
+        return false;
+    f.get();  // the single whitespace byte after maxval
+    std::vector<unsigned char> rgb((size_t)w * h * 3);
+    if (!f.read(reinterpret_cast<char*>(rgb.data()), (std::streamsize)rgb.size()))
+        return false;
+    rgba->resize((size_t)w * h * 4);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        (*rgba)[4 * i] = rgb[3 * i];
+        (*rgba)[4 * i + 1] = rgb[3 * i + 1];
+        (*rgba)[4 * i + 2] = rgb[3 * i + 2];
+        (*rgba)[4 * i + 3] = 255;
+    }
+    *width = w;
+    *height = h;
+    return true;
+}
+#endif
+
+void ProgramHandler::GetImageOpenCL(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width,
+                                    cl_int* height, Logger& logger)
+{
+#ifdef MI355_NO_OPENCV
+    if (!read_ppm_rgba(image_path, input_data, width, height))
+        logger.log("Failed to load image", Logger::LogLevel::ERROR);
+#else
+    cv::Mat image = cv::imread(image_path, cv::IMREAD_COLOR);
+    if (image.empty()) {
+        logger.log("Failed to load image", Logger::LogLevel::ERROR);
+        return;
+    }
+    if (DISPLAY_IMAGES)
+        cv::imshow("Reference Image Window", image);
+    cv::cvtColor(image, image, cv::COLOR_BGR2RGBA);
+    *width = image.cols;
+    *height = image.rows;
+    input_data->assign(image.data, image.data + image.total() * 4);
+#endif
+}
+
+static int method_index(const std::string& method)
+{
+    if (method == "EDGE")
+        return 1;
+    if (method == "GAUSSIAN")
+        return 2;
+    return 0;  // the reference treats everything else as GRAYSCALE (:171-175)
+}
+
+std::vector<unsigned char> ProgramHandler::PerformOpenCL(
+    Controller& controller, std::string image_path, cl_context* context, cl_command_queue* command_queue,
+    cl_kernel* kernel, double& avg_opencl_execution_time, double& avg_opencl_kernel_write_time,
+    double& avg_opencl_kernel_execution_time, double& avg_opencl_kernel_read_time, double& avg_opencl_kernel_operation,
+    cl_int& width, cl_int& height, Logger& logger, std::string method)
+{
+    std::vector<unsigned char> input_data;
+    std::vector<unsigned char> function_output;
+    width = height = 0;
+    GetImageOpenCL(image_path, &input_data, &width, &height, logger);
+    const int which = method_index(method);
+    const size_t npx = (size_t)width * height;
+
+    double total_execution_time = 0.0, total_write_time = 0.0, total_kernel_time = 0.0, total_read_time = 0.0;
+    for (int i = 0; i < NUMBER_OF_ITERATIONS; i++) {
+        std::vector<cl_ulong> ev;
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        switch (which) {
+        case 0:
+            function_output = std::vector<unsigned char>(npx * 4);
+            controller.PerformCLImageGrayscaling(context, command_queue, kernel, &ev, &input_data, &function_output,
+                                                 width, height, logger);
+            break;
+        case 1:
+            function_output = std::vector<unsigned char>(npx);
+            controller.PerformCLImageEdgeDetection(context, command_queue, kernel, &ev, &input_data,
+                                                   &function_output, width, height, logger);
+            break;
+        default:
+            function_output = std::vector<unsigned char>(npx * 4);
+            controller.PerformCLGaussianBlur(GAUSSIAN_KERNEL_SIZE, GAUSSIAN_SIGMA, context, command_queue, kernel,
+                                             &ev, &input_data, &function_output, width, height, logger);
+            break;
+        }
+        logger.log("Performing OpenCL " + method + " on " + image_path + "...", Logger::LogLevel::INFO);
+        const auto t1 = std::chrono::high_resolution_clock::now();
+        total_execution_time += std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (ev.size() >= 6) {
+            total_write_time += (ev[1] - ev[0]) * 1e-6;
+            total_kernel_time += (ev[3] - ev[2]) * 1e-6;
+            total_read_time += (ev[5] - ev[4]) * 1e-6;
+            if (LOG_EVENTS) {
+                static const char* names[6] = {"Write event start: ", "Write event end: ", "Kernel event start: ",
+                                               "Kernel event end: ", "Read event start: ",  "Read event end: "};
+                for (int e = 0; e < 6; e++)
+                    logger.log(names[e] + std::to_string(ev[e]), Logger::LogLevel::INFO);
+            }
+        }
+    }
+    logger.log("OpenCL " + method + " conversion complete", Logger::LogLevel::INFO);
+
+    const double n = NUMBER_OF_ITERATIONS > 0 ? NUMBER_OF_ITERATIONS : 1;
+    avg_opencl_execution_time = total_execution_time / n;
+    avg_opencl_kernel_write_time = total_write_time / n;
+    avg_opencl_kernel_execution_time = total_kernel_time / n;
+    avg_opencl_kernel_read_time = total_read_time / n;
+    avg_opencl_kernel_operation = (total_write_time + total_kernel_time + total_read_time) / n;
+    return function_output;
+}
+
+std::vector<unsigned char> ProgramHandler::PerformOpenCL(Controller& controller, const cv::Mat& input_frame,
+                                                         cl_context* context, cl_command_queue* command_queue,
+                                                         cl_kernel* kernel, cl_int& width, cl_int& height,
+                                                         Logger& logger, std::string method)
+{
+    assert(input_frame.cols == width && input_frame.rows == height);
+    std::vector<cl_ulong> profiling_events;
+    std::vector<unsigned char> function_output;
+    // the frame must already be RGBA (RT/RealtimeImageProcessing.cpp:330)
+    std::vector<unsigned char> input_data(input_frame.data, input_frame.data + input_frame.total() * 4);
+    const size_t npx = (size_t)width * height;
+
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    switch (method_index(method)) {
+    case 0:
+        function_output = std::vector<unsigned char>(npx * 4);
+        logger.log("Performing OpenCL Grayscaling...", Logger::LogLevel::INFO);
+        controller.PerformCLImageGrayscaling(context, command_queue, kernel, &profiling_events, &input_data,
+                                             &function_output, width, height, logger);
+        logger.log("OpenCL Grayscale conversion complete", Logger::LogLevel::INFO);
+        break;
+    case 1:
+        function_output = std::vector<unsigned char>(npx);
+        logger.log("Performing OpenCL Edge Detection...", Logger::LogLevel::INFO);
+        controller.PerformCLImageEdgeDetection(context, command_queue, kernel, &profiling_events, &input_data,
+                                               &function_output, width, height, logger);
+        logger.log("OpenCL Edge Detection complete", Logger::LogLevel::INFO);
+        break;
+    default:
+        function_output = std::vector<unsigned char>(npx * 4);
+        logger.log("Performing OpenCL Gaussian Blur...", Logger::LogLevel::INFO);
+        controller.PerformCLGaussianBlur(GAUSSIAN_KERNEL_SIZE, GAUSSIAN_SIGMA, context, command_queue, kernel,
+                                         &profiling_events, &input_data, &function_output, width, height, logger);
+        logger.log("OpenCL Gaussian Blur complete", Logger::LogLevel::INFO);
+        break;
+    }
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    logger.log("OpenCL " + method + " execution time: " + std::to_string(ms) + " ms", Logger::LogLevel::INFO);
+    return function_output;
+}
