@@ -44,3 +44,29 @@ for f in find("pmc*/**/*counter_collection.csv"):
         if "gauss" in k or "sobel" in k or "gray" in k or "pipeline" in k:
             for c, v in cs.items():
                 print("%-60s %-24s n=%3d mean=%.6g" % (k[:60], c, len(v), sum(v) / len(v)))
+
+# HBM traffic per launch of the dominant filter kernel, corrected as MI355X_MICROARCH.md "HBM" prescribes:
+# FETCH_SIZE (KiB) counts a wide coalesced 16 B/lane read at exactly half on gfx950 -> x2; WRITE_SIZE (KiB)
+# reads exact for 16 B/lane streaming stores.
+import json
+fetch = write = None
+kname = None
+for f in find("pmc*/**/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if any(t in k for t in ("gauss", "sobel", "gray", "pipeline")):
+            kname = k
+            if r["Counter_Name"] == "FETCH_SIZE":
+                fetch = (fetch or []) + [float(r["Counter_Value"])]
+            if r["Counter_Name"] == "WRITE_SIZE":
+                write = (write or []) + [float(r["Counter_Value"])]
+if fetch and write:
+    fb = 2.0 * 1024.0 * sum(fetch) / len(fetch)
+    wb = 1024.0 * sum(write) / len(write)
+    rec = {"kernel": kname, "fetch_size_kib_mean": sum(fetch) / len(fetch), "write_size_kib_mean": sum(write) / len(write),
+           "hbm_read_bytes_per_launch": fb, "hbm_write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
+           "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 half-count of wide coalesced reads), write = WRITE_SIZE x 1024",
+           "bench_args": sys.argv[2] if len(sys.argv) > 2 else ""}
+    print("== traffic ==")
+    print(json.dumps(rec, indent=1))
+    json.dump(rec, open(os.path.join(out, "traffic.json"), "w"), indent=1)
