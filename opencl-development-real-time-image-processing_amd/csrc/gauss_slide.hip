@@ -20,6 +20,8 @@
 //    pixel into the halo lane at load time, so the arithmetic itself has no border cases.
 // Algorithmic bytes: 8 B/px.  Extra traffic: halo lanes (2/62 of the loads, L2/MALL hits) and 2R
 // warm-up rows per band.  VALU: 2*K FMA per channel + 1 cvt in + 1 cvt/pack out.  Bound: HBM.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -57,6 +59,49 @@ __device__ __forceinline__ float ubyte_f32(uint32_t p, int c)
 // float -> u8 as uchar(std::clamp(v, 0.f, 255.f)).  The sums here are >= 0 and NaN-free (non-negative
 // weights times u8), so only the upper clamp can matter, and it cannot when 255 * (sum of weights)^2
 // < 256: the launcher selects CLAMP = false for such tables (every normalised Gaussian).
+// Truncate 4 pixels x 4 channels of floats in [0, 256) to bytes and merge each pixel into one dword in
+// 16 instructions: v_cvt_u32_f32 for byte 0, then SDWA conversions that write byte 1..3 of the same
+// register and preserve the rest.  (Measured on gfx950: every non-FMA VALU op costs ~3 cycles at 4
+// waves/SIMD, so the compiler's cvt + shift/or sequence, 7 ops per pixel, is worth replacing.)
+// gfx940-class "dst_sel forwarding" hazard: a VALU op that reads a VGPR right after a sub-dword (SDWA)
+// write of it needs a wait state, and hipcc does not look inside an asm statement — so the four pixels
+// are interleaved (three instructions between two partial writes of one register) and the block ends
+// with an s_nop before anything else can read the results.  A back-to-back version loses a byte.
+__device__ __forceinline__ void cvt_pack4x4(const float (&h)[4][4] /* [channel][pixel] */, u32x4& o)
+{
+    uint32_t o0, o1, o2, o3;
+    asm("v_cvt_u32_f32_e32 %0, %4\n\t"
+        "v_cvt_u32_f32_e32 %1, %5\n\t"
+        "v_cvt_u32_f32_e32 %2, %6\n\t"
+        "v_cvt_u32_f32_e32 %3, %7\n\t"
+        "v_cvt_u32_f32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %1, %9 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %2, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %3, %11 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %0, %12 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %1, %13 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %2, %14 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %3, %15 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %0, %16 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %1, %17 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %2, %18 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %3, %19 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "s_nop 1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(h[0][0]), "v"(h[0][1]), "v"(h[0][2]), "v"(h[0][3]), "v"(h[1][0]), "v"(h[1][1]), "v"(h[1][2]),
+          "v"(h[1][3]), "v"(h[2][0]), "v"(h[2][1]), "v"(h[2][2]), "v"(h[2][3]), "v"(h[3][0]), "v"(h[3][1]),
+          "v"(h[3][2]), "v"(h[3][3]));
+    o = u32x4{o0, o1, o2, o3};
+}
+
+template <bool CLAMP>
+__device__ __forceinline__ uint32_t to_u8(float a)
+{
+    if constexpr (CLAMP)
+        a = fminf(a, 255.0f);
+    return (uint32_t)a;
+}
+
 template <bool CLAMP>
 __device__ __forceinline__ uint32_t pack_px(float a, float b, float c, float d)
 {
@@ -67,6 +112,44 @@ __device__ __forceinline__ uint32_t pack_px(float a, float b, float c, float d)
         d = fminf(d, 255.0f);
     }
     return (uint32_t)a | ((uint32_t)b << 8) | ((uint32_t)c << 16) | ((uint32_t)d << 24);
+}
+
+// Horizontal 5-tap pass of ONE channel of a lane's 4 pixels, taps from the neighbouring lanes fused
+// into the multiply-adds as DPP operands (v_mul_f32_dpp / v_fmac_f32_dpp, wave_shr:1 = value of lane-1,
+// wave_shl:1 = value of lane+1).  hipcc fuses the DPP move into v_mul but not into v_fmac, and the
+// separate v_mov_b32_dpp cost 16 VALU + 16 VGPRs per row, hence this block.  Same op order as the generic
+// code path (o = w0*s0; o = fma(w_t, s_t, o)), so results are bit-identical.
+//  * `s_nop 1` first: a VGPR written by VALU needs 2 wait states before a DPP read of it, and the
+//    hazard recogniser does not look inside an asm statement.  Inside the block no DPP source is written.
+//  * volatile: the block must execute with the full EXEC mask of the wave (a DPP read of a disabled lane
+//    returns 0), so it must not be sunk into the store-predicated region.
+__device__ __forceinline__ void hpass5_dpp(float v0, float v1, float v2, float v3, float w0, float w1, float w2,
+                                           float w3, float w4, float& o0, float& o1, float& o2, float& o3)
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %6, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_dpp %1, %7, %8 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_mul_f32_e32 %2, %8, %4\n\t"
+        "v_mul_f32_e32 %3, %8, %5\n\t"
+        "v_fmac_f32_dpp %0, %7, %9 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_e32 %1, %9, %4\n\t"
+        "v_fmac_f32_e32 %2, %9, %5\n\t"
+        "v_fmac_f32_e32 %3, %9, %6\n\t"
+        "v_fmac_f32_e32 %0, %10, %4\n\t"
+        "v_fmac_f32_e32 %1, %10, %5\n\t"
+        "v_fmac_f32_e32 %2, %10, %6\n\t"
+        "v_fmac_f32_e32 %3, %10, %7\n\t"
+        "v_fmac_f32_e32 %0, %11, %5\n\t"
+        "v_fmac_f32_e32 %1, %11, %6\n\t"
+        "v_fmac_f32_e32 %2, %11, %7\n\t"
+        "v_fmac_f32_dpp %3, %4, %11 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_e32 %0, %12, %6\n\t"
+        "v_fmac_f32_e32 %1, %12, %7\n\t"
+        "v_fmac_f32_dpp %2, %4, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_fmac_f32_dpp %3, %5, %12 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
 }
 
 template <int R, bool CLAMP>
@@ -119,9 +202,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
         return *reinterpret_cast<const u32x4*>(rowp + in_off);
     };
 
+    // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
+    // only PF of the K slots are live at a time (PF x 1 KiB in flight per wave)
+    constexpr int PF = (K < 3) ? K : 3;
     u32x4 q[K];
 #pragma unroll
-    for (int u = 0; u < K; u++)
+    for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
     float acc[K][16] = {};
@@ -134,7 +220,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
         for (int u = 0; u < K; u++) {
             const int i = base + u;
             u32x4 p = q[u];
-            q[u] = load_row(i + K);
+            q[(u + PF) % K] = load_row(i + PF);
             if (edge_strip) {
                 // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
                 if (left_of_image)
@@ -142,45 +228,62 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
                 if (right_of_image)
                     p = u32x4{p.w, p.w, p.w, p.w};
             }
-            float f[16];
+            // vertical pass, pixel by pixel: convert one pixel's 4 channels, fold them into all K
+            // accumulators (input row i is tap j of output row i - j), then move on — 4 live temporaries
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                f[0 + c] = ubyte_f32(p.x, c);
-                f[4 + c] = ubyte_f32(p.y, c);
-                f[8 + c] = ubyte_f32(p.z, c);
-                f[12 + c] = ubyte_f32(p.w, c);
-            }
+            for (int px = 0; px < 4; px++) {
+                float f[4];
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                const int s = (u - j + K) % K;
+                for (int c = 0; c < 4; c++)
+                    f[c] = ubyte_f32(p[px], c);
 #pragma unroll
-                for (int e = 0; e < 16; e++)
-                    acc[s][e] = (j == 0) ? wv[0] * f[e] : __builtin_fmaf(wv[j], f[e], acc[s][e]);
+                for (int j = 0; j < K; j++) {
+                    const int s = (u - j + K) % K;
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        acc[s][px * 4 + c] =
+                            (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], acc[s][px * 4 + c]);
+                }
             }
             const int m = i - 2 * R;  // output row that just received its last tap
             const float* v = acc[(u + 1) % K];
             u32x4 o;
+            if constexpr (R == 2) {
+                float hres[4][4];  // [channel][pixel]
 #pragma unroll
-            for (int px = 0; px < 4; px++) {
-                float r4[4];
+                for (int c = 0; c < 4; c++)
+                    hpass5_dpp(v[0 + c], v[4 + c], v[8 + c], v[12 + c], wv[0], wv[1], wv[2], wv[3], wv[4],
+                               hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
+                if constexpr (CLAMP) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    float sum = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < K; t++) {
-                        const int s = px - R + t;
-                        float src;
-                        if (s < 0)
-                            src = dpp_from_left(v[(4 + s) * 4 + c]);
-                        else if (s > 3)
-                            src = dpp_from_right(v[(s - 4) * 4 + c]);
-                        else
-                            src = v[s * 4 + c];
-                        sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
-                    }
-                    r4[c] = sum;
+                    for (int px = 0; px < 4; px++)
+                        o[px] = pack_px<true>(hres[0][px], hres[1][px], hres[2][px], hres[3][px]);
+                } else {
+                    cvt_pack4x4(hres, o);
                 }
-                o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
+            } else {
+#pragma unroll
+                for (int px = 0; px < 4; px++) {
+                    float r4[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < K; t++) {
+                            const int s = px - R + t;
+                            float src;
+                            if (s < 0)
+                                src = dpp_from_left(v[(4 + s) * 4 + c]);
+                            else if (s > 3)
+                                src = dpp_from_right(v[(s - 4) * 4 + c]);
+                            else
+                                src = v[s * 4 + c];
+                            sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                        }
+                        r4[c] = sum;
+                    }
+                    o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
+                }
             }
             if (stores && m >= 0 && m < nout) {
                 uint8_t* rowp = fout + (size_t)(y0 + m) * row_bytes;
@@ -201,6 +304,8 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     // bands: ~128 rows amortise the 2R warm-up rows to a few percent while leaving >> 256 CUs x 12
     // waves of work for a batch of 4K frames
     int band_rows = 128;
+    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
+        band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
     if (h < band_rows)
         band_rows = h;
     const int nbands = (h + band_rows - 1) / band_rows;

@@ -39,14 +39,16 @@ __global__ __launch_bounds__(256) void copy_chunk_k(const u32x4* __restrict__ in
 }
 
 // sliding-window shape: wave = strip of 64 lanes x 16 B, walks `rows` rows at pitch `quads` (in 16-B units)
-template <int K, int LDNT, int STNT>
+template <int K, int LDNT, int STNT, int LANES, int HALO>
 __global__ __launch_bounds__(256) void rows_k(const u32x4* __restrict__ in, u32x4* __restrict__ out, int quads, int h, int nstrips, int band_rows, int nbands, uint32_t nwork)
 {
     uint32_t work = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (work >= nwork) return;
     int lane = threadIdx.x & 63;
     int strip = work % nstrips, band = (work / nstrips) % nbands; size_t frame = work / (nstrips * nbands);
-    int q = strip * 60 + lane; if (q >= quads) q = quads - 1;
+    int q = strip * LANES + lane - (LANES < 64 ? 1 : 0); if (q >= quads) q = quads - 1; if (q < 0) q = 0;
+    int qh = strip * LANES + (lane == 0 ? -1 : LANES); if (qh < 0) qh = 0; if (qh >= quads) qh = quads - 1;
+    const u32x4* hin = in + frame * (size_t)quads * h + qh;
     const u32x4* fin = in + frame * (size_t)quads * h + q; u32x4* fout = out + frame * (size_t)quads * h + q;
     int y0 = band * band_rows; int n = band_rows; if (y0 + n > h) n = h - y0;
     u32x4 r[K];
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(256) void rows_k(const u32x4* __restrict__ in, u32x
             int i = base + u; u32x4 p = r[u];
             int yn = y0 + (i + K < n ? i + K : n - 1);
             r[u] = LDNT ? __builtin_nontemporal_load(fin + (size_t)yn * quads) : fin[(size_t)yn * quads];
+            if (HALO) { if (lane == 0 || lane == 63) { u32x4 hv = hin[(size_t)(y0 + (i < n ? i : n - 1)) * quads]; p.y ^= hv.x; } }
             p.x ^= 0x01010101u;
-            if (i < n && lane < 60) { if (STNT) __builtin_nontemporal_store(p, fout + (size_t)(y0 + i) * quads); else fout[(size_t)(y0 + i) * quads] = p; }
+            if (i < n && (LANES == 64 || (lane >= 1 && lane <= LANES))) { if (STNT) __builtin_nontemporal_store(p, fout + (size_t)(y0 + i) * quads); else fout[(size_t)(y0 + i) * quads] = p; }
         }
     }
 }
@@ -94,14 +97,23 @@ int main(int argc, char** argv)
         printf("copy chunked per_block=%6zu x16B (%u blocks): plain %7.1f | nt %7.1f GB/s\n", per_block, blocks, gbs(a), gbs(b));
     }
     {
-        int nstrips = 16, band_rows = 128, nbands = (h + band_rows - 1) / band_rows;
-        uint32_t nwork = nstrips * nbands * frames; unsigned blocks = (nwork + 3) / 4;
-        float a = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
-        float b = timeit([&] { hipLaunchKernelGGL((rows_k<5, 1, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
-        float c = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
-        float d = timeit([&] { hipLaunchKernelGGL((rows_k<8, 0, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
-        float e = timeit([&] { hipLaunchKernelGGL((rows_k<2, 0, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
-        printf("rows shape (strip 60 lanes, band 128): K5 plain %7.1f | K5 nt/nt %7.1f | K5 ld plain st nt %7.1f | K8 %7.1f | K2 %7.1f GB/s\n", gbs(a), gbs(b), gbs(c), gbs(d), gbs(e));
+        int band_rows = 128, nbands = (h + band_rows - 1) / band_rows;
+        {
+            int nstrips = 16; uint32_t nwork = nstrips * nbands * frames; unsigned blocks = (nwork + 3) / 4;
+            float a = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 0, 60, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float c = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 1, 60, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float b = timeit([&] { hipLaunchKernelGGL((rows_k<5, 1, 1, 60, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            printf("rows 60-lane strips + halo lanes: plain %7.1f | st nt %7.1f | nt/nt %7.1f GB/s\n", gbs(a), gbs(c), gbs(b));
+        }
+        {
+            int nstrips = 15; uint32_t nwork = nstrips * nbands * frames; unsigned blocks = (nwork + 3) / 4;
+            float a = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 0, 64, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float c = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 1, 64, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float b = timeit([&] { hipLaunchKernelGGL((rows_k<5, 1, 1, 64, 0>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float d = timeit([&] { hipLaunchKernelGGL((rows_k<5, 0, 1, 64, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            float e = timeit([&] { hipLaunchKernelGGL((rows_k<8, 0, 1, 64, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
+            printf("rows 64-lane aligned strips: plain %7.1f | st nt %7.1f | nt/nt %7.1f | st nt + 2-lane halo loads %7.1f | same K8 %7.1f GB/s\n", gbs(a), gbs(c), gbs(b), gbs(d), gbs(e));
+        }
     }
     float m = timeit([&] { hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0); }, 5);
     printf("hipMemcpy D2D: %7.1f GB/s\n", gbs(m));
