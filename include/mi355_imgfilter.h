@@ -64,10 +64,10 @@ const char* mi355_strerror(int code);
 
 int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
 
-/* Kernel selection for the FAST Gaussian (a tuning / test knob; results are bit-identical):
- *   AUTO — register-resident sliding-window kernel when k in {3,5,7,9}, width % 4 == 0 and both
- *          buffers are 16-byte aligned; the LDS-tiled kernel otherwise.
- *   TILE — always the LDS-tiled kernel. */
+/* Kernel selection (a tuning / test knob; results are bit-identical):
+ *   AUTO — the register-resident sliding-window kernels when they apply (width % 4 == 0, 16-byte aligned
+ *          buffers; Gaussian additionally k in {3,5,7,9} and FAST mode); the LDS-tiled kernels otherwise.
+ *   TILE — always the LDS-tiled kernels. */
 #define MI355_GAUSS_IMPL_AUTO 0
 #define MI355_GAUSS_IMPL_TILE 1
 int mi355_ctx_set_gauss_impl(mi355_ctx* ctx, int impl);

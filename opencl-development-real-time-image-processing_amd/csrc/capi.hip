@@ -224,10 +224,10 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
         e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->gauss_impl);
         break;
     case MI355_FILTER_SOBEL:
-        e = launch_sobel(ctx->stream, in, out, w, h, nframes);
+        e = launch_sobel(ctx->stream, in, out, w, h, nframes, ctx->gauss_impl);
         break;
     case MI355_FILTER_PIPELINE:
-        e = launch_pipeline(ctx->stream, in, out, w, h, nframes, *coef, exact);
+        e = launch_pipeline(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->gauss_impl);
         break;
     default:
         return MI355_ERR_BAD_ARG;

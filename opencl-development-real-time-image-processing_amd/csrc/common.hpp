@@ -32,6 +32,39 @@ __device__ __forceinline__ uint32_t luma_px(uint32_t px)
     return luma_rgb(px & 0xFFu, (px >> 8) & 0xFFu, (px >> 16) & 0xFFu);
 }
 
+// Same value as luma_px without FP64 on the common path (FP64 ops issue at ~5.7 cycles per wave64 on
+// gfx950, fp32 add/fma at 2, everything else at ~3).  With S = 299r + 587g + 114b the double-precision sum
+// truncates to floor(S/1000) for every colour except some with S % 1000 == 0, where it can land just below
+// the integer (3,464 of the 2^24 colours; checked exhaustively on CPU and on GPU).  So: q = floor(S/1000)
+// exactly, and only pixels with S == 1000q (0.1 % of colours) take the FP64 formula.
+//   S       = 256 (r + 2g) + (43r + 75g + 114b)       two v_dot4_u32_u8 + one shift-add, exact integer
+//   q       = floor(S * 0.001f + 0.0005f)              S/1000 = n + j/1000, so +0.0005 keeps the argument
+//                                                      >= 0.0005 away from an integer; float error < 4e-5
+// Returns q as a float (all callers continue in fp32, where these small integers are exact).
+__device__ __forceinline__ float luma_px_fast(uint32_t px)
+{
+    const uint32_t hi = __builtin_amdgcn_udot4(px, 0x00000201u, 0u, false);
+    const uint32_t lo = __builtin_amdgcn_udot4(px, 0x00724B2Bu, 0u, false);
+    const float S = (float)((hi << 8) + lo);  // <= 255000 < 2^24: exact
+    float q = __builtin_floorf(__builtin_fmaf(S, 0.001f, 0.0005f));
+    if (__builtin_fmaf(q, -1000.0f, S) == 0.0f)  // exact test; rare: the reference formula picks q or q - 1
+        q = (float)luma_px(px);
+    return q;
+}
+
+// min(255, round-half-even(sqrt(gx^2 + gy^2))) for integer-valued floats |gx|, |gy| <= 1020, without
+// integer fix-ups: with s = gx^2 + gy^2 (exact in fp32), round(sqrt(s)) = floor(0.5 + 0.5 * sqrt(4s - 1))
+// for s >= 1 — 4s-1 is never a perfect square and the argument of floor stays >= 1/511 away from an integer
+// for results <= 255, far more than the error of v_sqrt_f32.  Brute-forced against the exact integer form
+// for every s < 2^21, also with a +-2 ulp sqrt.  Returned as float in [0, 255].
+__device__ __forceinline__ float sobel_mag_fast(float gx, float gy)
+{
+    const float s = __builtin_fmaf(gx, gx, gy * gy);
+    const float t = fmaxf(__builtin_fmaf(4.0f, s, -1.0f), 0.0f);
+    const float u = __builtin_amdgcn_sqrtf(t);
+    return fminf(__builtin_floorf(__builtin_fmaf(u, 0.5f, 0.5f)), 255.0f);
+}
+
 __device__ __forceinline__ uint32_t gray_to_rgba(uint32_t g)
 {
     return g * 0x00010101u | 0xFF000000u;

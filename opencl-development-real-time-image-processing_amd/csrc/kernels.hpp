@@ -33,11 +33,17 @@ bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
 hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                               int nframes, const GaussCoef& coef);
 
+// impl: 0 = choose (sliding window when width % 4 == 0 and buffers aligned), 1 = force the LDS-tiled kernel
 hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                        int nframes);
+                        int nframes, int impl);
+bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h);
+hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes);
 
 hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                           int nframes, const GaussCoef& coef, bool exact);
+                           int nframes, const GaussCoef& coef, bool exact, int impl);
+bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                             const GaussCoef& coef);
 
 hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nframes,
                         int first_frame, uint32_t seed, int mode);

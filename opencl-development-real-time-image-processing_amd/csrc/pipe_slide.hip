@@ -1,0 +1,254 @@
+// pipe_slide.hip — fused gray -> Gaussian -> Sobel on RGBA8 frames, register-resident sliding window,
+// FAST Gaussian arithmetic, k in {3,5,7}, width % 4 == 0, height >= 2.  gfx950 only.
+//
+// Definition (SURVEY.md §8a "a-pipe", oracle_pipeline_rgba): exactly the composition of the three API calls
+//   g = luma(R,G,B)                                   src/Grayscale/grayscale.cpp:237
+//   b = trunc(clamp(Gaussian_k(g)))  clamp-to-edge     src/GaussianBlur/GaussianBlur.cpp:234-261 on (g,g,g,255)
+//   l = luma(b,b,b)                  RE-APPLIED        (l != b for 65 byte values)
+//   out = Sobel(l)                   reflect-101       src/EdgeDetection/EdgeDetection.cpp:219-240
+// and, because the Gaussian uses the canonical FAST op order of gauss_slide.hip / gauss_tile.hip, the output
+// is bit-identical to mi355_sobel(mi355_gauss(mi355_gray(x))) of this library (tests/test_gpu_parity.py).
+//
+// One wave per (frame, band, strip of <= 62 lanes + 1 halo lane per side), a lane owns 4 pixels:
+//   row in -> luma (4 floats) -> K vertical accumulators (4 floats each) -> finished vertical sum ->
+//   horizontal taps (neighbour lanes through DPP) -> trunc -> l = LUT[b] (256-byte table in LDS: luma(b,b,b)
+//   always sits on the ambiguous S % 1000 == 0 case, so it is tabulated once per workgroup with the FP64
+//   formula) -> 3-row ring of l -> Sobel row in fp32 -> 4 bytes stored.
+// 4 B read + 1 B written per pixel; nothing intermediate touches memory (the three separate calls move
+// 8 + 8 + 5 B/px).  Border rules: gray columns/rows clamp (replicated halo lane / clamped row index); the
+// blurred image reflects: column x=-1 takes x=1 and x=w takes x=w-2 by a DPP fix-up in the two edge strips,
+// row -1 takes row 1 and row h takes row h-2 by swapping ring slots at the first / last image row.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kLanesOutMax = 62;
+constexpr int kWavesPerBlock = 4;
+
+template <int K>
+struct PWeights {
+    float w[K];
+};
+
+__device__ __forceinline__ float dppl(float v)  // lane l <- lane l-1
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+template <int R, bool CLAMP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
+    int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks, PWeights<2 * R + 1> wts)
+{
+    constexpr int K = 2 * R + 1;
+    __shared__ uint8_t lut[256];  // lut[b] = luma(b, b, b), the reference double-precision formula
+    lut[threadIdx.x] = (uint8_t)luma_rgb(threadIdx.x, threadIdx.x, threadIdx.x);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
+    const uint32_t work =
+        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
+    if (work >= nwork)
+        return;  // after the only barrier
+    const int strip = work % nstrips;
+    const int band = (work / nstrips) % nbands;
+    const size_t frame = work / ((uint32_t)nstrips * nbands);
+
+    const int q_lane = strip * lanes_out + lane - 1;
+    const int q_load = clampi(q_lane, 0, quads - 1);
+    const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
+    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    const int q_end = min((strip + 1) * lanes_out, quads);
+    const bool stores = (lane >= 1) && (q_lane < q_end);
+
+    const int y0 = band * band_rows;
+    const int nout = min(band_rows, h - y0);
+    // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R
+    const int nin = nout + 2 + 2 * R;
+
+    const size_t row_bytes = (size_t)quads * 16;
+    const uint8_t* fin = in + frame * row_bytes * h;
+    uint8_t* fout = out + frame * (size_t)quads * 4 * h;
+    const uint32_t in_off = (uint32_t)q_load * 16u;
+    const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
+
+    float wv[K];
+#pragma unroll
+    for (int j = 0; j < K; j++)
+        wv[j] = wts.w[j];
+
+    auto load_row = [&](int i) -> u32x4 {
+        const int y = clampi(y0 - 1 - R + min(i, nin - 1), 0, h - 1);  // gray rows: clamp-to-edge
+        return *reinterpret_cast<const u32x4*>(fin + (size_t)y * row_bytes + in_off);
+    };
+
+    constexpr int PF = 3;
+    // one trip of the unrolled loop = LCM(K, 3) = 3K rows would be needed to make both rings static; instead
+    // the Sobel ring (3 rows) is rotated by register moves (12 v_mov per row) and only the K-ring is static
+    u32x4 q[K];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        q[u] = load_row(u);
+
+    float acc[K][4] = {};
+    float lt[4] = {}, lm[4] = {};  // l rows: top, middle (bottom is produced in the current step)
+
+    for (int base = 0; base < nin; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int i = base + u;
+            u32x4 p = q[u];
+            q[(u + PF) % K] = load_row(i + PF);
+            if (edge_strip) {
+                if (left_of_image)
+                    p = u32x4{p.x, p.x, p.x, p.x};  // gray image clamps: replicate column 0
+                if (right_of_image)
+                    p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
+            }
+            float g[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                g[j] = luma_px_fast(p[j]);
+            // vertical pass (canonical order): gray row i is tap j of blurred row i - j
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int s = (u - j + K) % K;
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    acc[s][e] = (j == 0) ? wv[0] * g[e] : __builtin_fmaf(wv[j], g[e], acc[s][e]);
+            }
+            const float* v = acc[(u + 1) % K];  // vertical sum of blurred row index rb = i - 2R (band-relative)
+            // horizontal pass (canonical order), neighbour-lane taps through DPP
+            float lb[4];
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+                    const int s = px - R + t;
+                    const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
+                    sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                }
+                if constexpr (CLAMP)
+                    sum = fminf(sum, 255.0f);
+                const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
+                lb[px] = (float)lut[bq];            // luma(b,b,b) re-applied
+            }
+            if (edge_strip) {
+                // the blurred image reflects (BORDER_REFLECT_101): x = -1 <- x = 1, x = w <- x = w-2
+                const float from_right = dppr(lb[1]);  // lane+1's pixel 1
+                const float from_left = dppl(lb[2]);   // lane-1's pixel 2
+                if (left_of_image)
+                    lb[3] = from_right;
+                if (right_of_image)
+                    lb[0] = from_left;
+            }
+            // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
+            const int yb = y0 - 1 + i - 2 * R;
+            const int m = yb - 1;
+            // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the bottom
+            // row (h) is row h-2 = the top row.  (yb is wave-uniform.)
+            const bool first = (m == 0), last = (m == h - 1);
+            float cs[4], cd[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float top = first ? lb[j] : lt[j];
+                const float bot = last ? lt[j] : lb[j];
+                cs[j] = __builtin_fmaf(2.0f, lm[j], top) + bot;
+                cd[j] = bot - top;
+            }
+            const float csl = dppl(cs[3]), csr = dppr(cs[0]);
+            const float cdl = dppl(cd[3]), cdr = dppr(cd[0]);
+            const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
+            const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
+            const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
+            const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
+            const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
+            const uint32_t r = (uint32_t)sobel_mag_fast(gx0, gy0) | ((uint32_t)sobel_mag_fast(gx1, gy1) << 8) |
+                               ((uint32_t)sobel_mag_fast(gx2, gy2) << 16) |
+                               ((uint32_t)sobel_mag_fast(gx3, gy3) << 24);
+            if (stores && m >= y0 && m < y0 + nout)
+                __builtin_nontemporal_store(r,
+                                            reinterpret_cast<uint32_t*>(fout + (size_t)m * quads * 4 + out_off));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lt[j] = lm[j];
+                lm[j] = lb[j];
+            }
+        }
+    }
+}
+
+template <int R>
+hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                    const GaussCoef& coef)
+{
+    constexpr int K = 2 * R + 1;
+    const int quads = w / 4;
+    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
+    const int lanes_out = (quads + nstrips - 1) / nstrips;
+    int band_rows = 64;
+    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
+        band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
+    if (h < band_rows)
+        band_rows = h;
+    const int nbands = (h + band_rows - 1) / band_rows;
+    band_rows = (h + nbands - 1) / nbands;
+    const size_t nwork = (size_t)nstrips * nbands * nframes;
+    const size_t nblocks = (nwork + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (nblocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    PWeights<K> wts;
+    double wsum = 0.0;
+    for (int j = 0; j < K; j++) {
+        wts.w[j] = coef.h_w1d[j];
+        wsum += (double)coef.h_w1d[j];
+    }
+    const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);
+    if (clamp)
+        hipLaunchKernelGGL((pipe_slide_kernel<R, true>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork,
+                           (uint32_t)nblocks, wts);
+    else
+        hipLaunchKernelGGL((pipe_slide_kernel<R, false>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork,
+                           (uint32_t)nblocks, wts);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k)
+{
+    if (k != 3 && k != 5 && k != 7)
+        return false;
+    if ((w & 3) != 0 || h < 2)
+        return false;
+    return ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 3u) == 0);
+}
+
+hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                             const GaussCoef& coef)
+{
+    switch (coef.k) {
+    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef);
+    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef);
+    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mi355

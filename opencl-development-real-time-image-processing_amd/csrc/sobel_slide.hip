@@ -1,0 +1,169 @@
+// sobel_slide.hip — Sobel edge magnitude of RGBA8 frames, register-resident sliding window, one
+// wavefront per image strip (the shape of gauss_slide.hip).  gfx950 only; width % 4 == 0.
+//
+// Replaces kernel `sobel_edge_detection` (RT/kernel/edge_base.cl:1-57) + ConvertToUChar
+// (RT/src/Controller.cpp:76-85,605) with the semantics of the reference CPU path
+// (src/EdgeDetection/EdgeDetection.cpp:219-240, BORDER_REFLECT_101, round + saturate) on
+// gray = src/Grayscale/grayscale.cpp:237 of every pixel.  Bit-exact with the oracle.
+//
+//  * a lane owns 4 consecutive pixels (one global_load_dwordx4), a wave a strip of up to 62 lanes plus one
+//    halo lane per side, walking down a band of rows; each input row is loaded once, 3 rows in flight.
+//  * luminance once per pixel (integer fast path, FP64 only for the 0.1 % ambiguous colours), kept for
+//    three rows in registers; per row the column sums t+2m+b and differences b-t, then
+//    gx = cs[x+1]-cs[x-1], gy = cd[x-1]+2cd[x]+cd[x+1]; the x-1 / x+1 columns of the edge pixels come from
+//    the neighbouring lane through DPP (wave_shr:1 / wave_shl:1) — no LDS, no barrier.
+//  * reflect-101: rows by reflecting the wave-uniform row index; columns by loading the mirror pixel into
+//    the halo lane (x = -1 takes x = 1, x = w takes x = w-2), only in the two edge strips.
+//  * out = min(255, round(sqrt(gx^2+gy^2))) through the fix-up-free form in common.hpp; 4 results packed
+//    into one dword store per lane.
+// Algorithmic bytes: 5 B/px (4 read, 1 written).  Bound: HBM.
+#include <cstdlib>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kLanesOutMax = 62;
+constexpr int kWavesPerBlock = 4;
+
+__device__ __forceinline__ float dpp_left(float v)  // lane l <- lane l-1
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+
+__device__ __forceinline__ float dpp_right(float v)  // lane l <- lane l+1
+{
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
+    int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks)
+{
+    constexpr int K = 3;
+    const int lane = threadIdx.x & 63;
+    const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
+    const uint32_t work =
+        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
+    if (work >= nwork)
+        return;
+    const int strip = work % nstrips;
+    const int band = (work / nstrips) % nbands;
+    const size_t frame = work / ((uint32_t)nstrips * nbands);
+
+    const int q_lane = strip * lanes_out + lane - 1;
+    const int q_load = clampi(q_lane, 0, quads - 1);
+    const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
+    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    const int q_end = min((strip + 1) * lanes_out, quads);
+    const bool stores = (lane >= 1) && (q_lane < q_end);
+
+    const int y0 = band * band_rows;
+    const int nout = min(band_rows, h - y0);
+    const int nin = nout + 2;
+
+    const size_t row_bytes = (size_t)quads * 16;
+    const uint8_t* fin = in + frame * row_bytes * h;
+    uint8_t* fout = out + frame * (size_t)quads * 4 * h;  // one byte per pixel
+    const uint32_t in_off = (uint32_t)q_load * 16u;
+    const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
+
+    auto load_row = [&](int i) -> u32x4 {
+        const int y = reflect101(y0 - 1 + min(i, nin - 1), h);
+        return *reinterpret_cast<const u32x4*>(fin + (size_t)y * row_bytes + in_off);
+    };
+
+    constexpr int PF = 3;
+    u32x4 q[K];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        q[u] = load_row(u);
+
+    // luminance of the last three rows (integer-valued floats: the whole stencil runs in fp32, where
+    // these small integers are exact and add/fma are the cheapest VALU ops), slot = input row index % 3
+    float L[K][4] = {};
+
+    for (int base = 0; base < nin; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int i = base + u;
+            u32x4 p = q[u];
+            q[(u + PF) % K] = load_row(i + PF);
+            if (edge_strip) {
+                // BORDER_REFLECT_101 columns: the only halo pixel ever read is the one next to the image
+                if (left_of_image)
+                    p.w = p.y;  // x = -1  <-  x = 1   (lane holds pixels 0..3)
+                if (right_of_image)
+                    p.x = p.z;  // x = w   <-  x = w-2 (lane holds pixels w-4..w-1)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                L[u][j] = luma_px_fast(p[j]);
+
+            // rows i-2 (top), i-1 (middle), i (bottom) -> output row m = i - 2
+            const float* t = L[(u + 1) % K];
+            const float* md = L[(u + 2) % K];
+            const float* b = L[u];
+            float cs[4], cd[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cs[j] = __builtin_fmaf(2.0f, md[j], t[j]) + b[j];
+                cd[j] = b[j] - t[j];
+            }
+            const float csl = dpp_left(cs[3]), csr = dpp_right(cs[0]);
+            const float cdl = dpp_left(cd[3]), cdr = dpp_right(cd[0]);
+            const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
+            const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
+            const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
+            const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
+            const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
+            const uint32_t r = (uint32_t)sobel_mag_fast(gx0, gy0) | ((uint32_t)sobel_mag_fast(gx1, gy1) << 8) |
+                               ((uint32_t)sobel_mag_fast(gx2, gy2) << 16) |
+                               ((uint32_t)sobel_mag_fast(gx3, gy3) << 24);
+            const int m = i - 2;
+            if (stores && m >= 0 && m < nout)
+                __builtin_nontemporal_store(
+                    r, reinterpret_cast<uint32_t*>(fout + (size_t)(y0 + m) * quads * 4 + out_off));
+        }
+    }
+}
+
+}  // namespace
+
+bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h)
+{
+    (void)h;
+    if ((w & 3) != 0)
+        return false;
+    return ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 3u) == 0);
+}
+
+hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes)
+{
+    const int quads = w / 4;
+    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
+    const int lanes_out = (quads + nstrips - 1) / nstrips;
+    // 32-row bands: this kernel is light (50 VGPRs, 8 waves/SIMD), so short work items matter more than
+    // the 2/32 halo-row re-reads (measured: 4.49 TB/s at 32 rows vs 4.04 at 128 on 64 x 4K frames)
+    int band_rows = 32;
+    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
+        band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
+    if (h < band_rows)
+        band_rows = h;
+    const int nbands = (h + band_rows - 1) / band_rows;
+    band_rows = (h + nbands - 1) / nbands;
+    const size_t nwork = (size_t)nstrips * nbands * nframes;
+    const size_t nblocks = (nwork + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (nblocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sobel_slide_kernel, dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0, stream, d_in,
+                       d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork, (uint32_t)nblocks);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -183,8 +183,10 @@ __global__ __launch_bounds__(kThreads) void pipeline_tile_kernel(const uint32_t*
 }  // namespace
 
 hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                        int nframes)
+                        int nframes, int impl)
 {
+    if (impl != 1 && sobel_slide_supported(d_in, d_out, w, h))
+        return launch_sobel_slide(stream, d_in, d_out, w, h, nframes);
     const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
     const size_t ntiles = (size_t)tiles_x * tiles_y * nframes;
     if (ntiles > 0x7FFFFFFFull)
@@ -197,8 +199,10 @@ hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
 }
 
 hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                           int nframes, const GaussCoef& coef, bool exact)
+                           int nframes, const GaussCoef& coef, bool exact, int impl)
 {
+    if (!exact && impl != 1 && pipe_slide_supported(d_in, d_out, w, h, coef.k))
+        return launch_pipe_slide(stream, d_in, d_out, w, h, nframes, coef);
     const int k = coef.k, R = k / 2;
     const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;
     const size_t ntiles = (size_t)tiles_x * tiles_y * nframes;

@@ -121,6 +121,28 @@ def test_sobel_bit_exact(ctx, oracle, h, w):
     assert np.array_equal(ctx.sobel(img), oracle.sobel_rgba(img))
 
 
+@pytest.mark.parametrize("h,w", [(1, 4), (2, 8), (3, 12), (40, 252), (33, 248), (7, 256), (131, 500), (300, 1920),
+                                 (5, 3840)])
+def test_sobel_sliding_window_kernel(ctx, pkg, oracle, h, w):
+    """sobel_slide.hip (width % 4 == 0) against the oracle and against the LDS-tiled kernel."""
+    for seed, mode in ((h + w, None), (7, 1)):
+        img = rand_rgba(h, w, seed=seed) if mode is None else oracle.synth_rgba(w, h, 1, first_frame=seed, mode=1)[0]
+        ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+        tiled = ctx.sobel(img)
+        ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+        slide = ctx.sobel(img)
+        assert np.array_equal(slide, tiled)
+        assert np.array_equal(slide, oracle.sobel_rgba(img))
+
+
+def test_sobel_all_colours_through_the_integer_luma_path(ctx, oracle):
+    """The sliding kernel's luminance is integer arithmetic + an FP64 path for ambiguous colours: run all
+    2^24 colours through it (a 4096x4096 frame whose pixel (i, j) has colour index i*4096+j)."""
+    r, g, b = np.meshgrid(np.arange(256), np.arange(256), np.arange(256), indexing="ij")
+    rgba = np.stack([r, g, b, np.full_like(r, 255)], -1).astype(np.uint8).reshape(4096, 4096, 4)
+    assert np.array_equal(ctx.sobel(rgba), oracle.sobel_rgba(rgba))
+
+
 def test_sobel_known_answers(ctx):
     flat = np.full((20, 70, 4), 90, np.uint8)
     assert ctx.sobel(flat).max() == 0
@@ -145,6 +167,37 @@ def test_pipeline(ctx, pkg, oracle, h, w):
     fused = ctx.pipeline(img, k, sigma)
     chained = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
     assert np.array_equal(fused, chained), "fused kernel == the three API calls chained"
+
+
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0)])
+@pytest.mark.parametrize("h,w", [(2, 4), (3, 8), (5, 12), (40, 252), (70, 248), (67, 256), (131, 500), (200, 1920),
+                                 (9, 3840)])
+def test_pipeline_sliding_window_kernel(ctx, pkg, oracle, k, sigma, h, w):
+    """pipe_slide.hip (FAST, k <= 7, width % 4 == 0, h >= 2) == the LDS-tiled fused kernel == the three calls
+    chained; and it stays close to the CPU chain (the Gaussian stage may differ by 1 LSB before Sobel)."""
+    img = oracle.synth_rgba(w, h, 1, first_frame=h + k, mode=(h + w) & 1)[0]
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    tiled = ctx.pipeline(img, k, sigma)
+    chained_tiled = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    slide = ctx.pipeline(img, k, sigma)
+    chained = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
+    assert np.array_equal(tiled, chained_tiled)
+    assert np.array_equal(chained, chained_tiled)
+    assert np.array_equal(slide, tiled)
+    ref = oracle.pipeline_rgba(img, k, sigma)
+    # a 1-LSB difference in one blurred pixel moves gx, gy by at most 4 each: |d magnitude| <= 6
+    assert np.abs(slide.astype(int) - ref.astype(int)).max() <= 6
+    assert (slide != ref).mean() < 0.05
+
+
+def test_pipeline_sliding_window_batched_multi_band(ctx, pkg, oracle):
+    frames = oracle.synth_rgba(1000, 300, 3, first_frame=2, mode=1)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    tiled = ctx.pipeline(frames, 5, 1.5)
+    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    assert np.array_equal(ctx.pipeline(frames, 5, 1.5), tiled)
 
 
 def test_pipeline_other_kernels(ctx, pkg, oracle):

@@ -67,6 +67,25 @@ __global__ __launch_bounds__(256) void rows_k(const u32x4* __restrict__ in, u32x
     }
 }
 
+// read-only stream (optionally with a 1/4-size dword write per 16 B read, the Sobel traffic shape)
+template <int WRITE4, int LDNT>
+__global__ __launch_bounds__(256) void read_k(const u32x4* __restrict__ in, uint32_t* __restrict__ out, size_t n)
+{
+    size_t stride = (size_t)gridDim.x * 256, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t acc = 0;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) v[u] = LDNT ? __builtin_nontemporal_load(&in[i + u * stride]) : in[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            uint32_t x = v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+            if (WRITE4) __builtin_nontemporal_store(x, &out[i + u * stride]); else acc ^= x;
+        }
+    }
+    if (!WRITE4 && acc == 0x12345678u) out[threadIdx.x] = acc;
+}
+
 template <typename F> float timeit(F f, int reps)
 {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -114,6 +133,14 @@ int main(int argc, char** argv)
             float e = timeit([&] { hipLaunchKernelGGL((rows_k<8, 0, 1, 64, 1>), dim3(blocks), dim3(256), 0, 0, in, out, quads, h, nstrips, band_rows, nbands, nwork); }, 10);
             printf("rows 64-lane aligned strips: plain %7.1f | st nt %7.1f | nt/nt %7.1f | st nt + 2-lane halo loads %7.1f | same K8 %7.1f GB/s\n", gbs(a), gbs(c), gbs(b), gbs(d), gbs(e));
         }
+    }
+    for (int blocks : {2048, 8192, 16384}) {
+        float a = timeit([&] { hipLaunchKernelGGL((read_k<0, 0>), dim3(blocks), dim3(256), 0, 0, in, (uint32_t*)out, n); }, 10);
+        float b = timeit([&] { hipLaunchKernelGGL((read_k<0, 1>), dim3(blocks), dim3(256), 0, 0, in, (uint32_t*)out, n); }, 10);
+        float c = timeit([&] { hipLaunchKernelGGL((read_k<1, 0>), dim3(blocks), dim3(256), 0, 0, in, (uint32_t*)out, n); }, 10);
+        float d = timeit([&] { hipLaunchKernelGGL((read_k<1, 1>), dim3(blocks), dim3(256), 0, 0, in, (uint32_t*)out, n); }, 10);
+        printf("read-only blocks=%5d: plain %7.1f | nt %7.1f GB/s read ;  read + dword write (5 B/px shape): plain %7.1f | nt %7.1f GB/s total\n", blocks,
+               bytes / (a * 1e-3) / 1e9, bytes / (b * 1e-3) / 1e9, 1.25 * bytes / (c * 1e-3) / 1e9, 1.25 * bytes / (d * 1e-3) / 1e9);
     }
     float m = timeit([&] { hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, 0); }, 5);
     printf("hipMemcpy D2D: %7.1f GB/s\n", gbs(m));
