@@ -8,6 +8,8 @@
 // Pure streaming: 4 px (16 B) per lane per access, 4 independent accesses in flight per lane,
 // grid-stride over the flat pixel array (frames are tightly packed, so a batch is one array).
 // Algorithmic bytes: 8 B/px (RGBA out) or 5 B/px (1-channel out).  Bound: HBM.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -17,6 +19,8 @@ namespace {
 
 constexpr int kGrayThreads = 256;
 constexpr int kGrayIlp = 4;
+
+__device__ __forceinline__ uint32_t luma_fast_u32(uint32_t px) { return (uint32_t)luma_px_fast(px); }
 
 __device__ __forceinline__ uint32_t pack4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
@@ -37,8 +41,8 @@ __global__ __launch_bounds__(kGrayThreads) void gray_vec_kernel(const u32x4* __r
             p[u] = __builtin_nontemporal_load(&in[i + u * stride]);
 #pragma unroll
         for (int u = 0; u < kGrayIlp; u++) {
-            const uint32_t g0 = luma_px(p[u].x), g1 = luma_px(p[u].y);
-            const uint32_t g2 = luma_px(p[u].z), g3 = luma_px(p[u].w);
+            const uint32_t g0 = luma_fast_u32(p[u].x), g1 = luma_fast_u32(p[u].y);
+            const uint32_t g2 = luma_fast_u32(p[u].z), g3 = luma_fast_u32(p[u].w);
             if constexpr (ONE_CH) {
                 __builtin_nontemporal_store(pack4(g0, g1, g2, g3),
                                             &reinterpret_cast<uint32_t*>(out)[i + u * stride]);
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(kGrayThreads) void gray_vec_kernel(const u32x4* __r
     }
     for (; i < nquads; i += stride) {
         const u32x4 p = in[i];
-        const uint32_t g0 = luma_px(p.x), g1 = luma_px(p.y), g2 = luma_px(p.z), g3 = luma_px(p.w);
+        const uint32_t g0 = luma_fast_u32(p.x), g1 = luma_fast_u32(p.y), g2 = luma_fast_u32(p.z), g3 = luma_fast_u32(p.w);
         if constexpr (ONE_CH) {
             reinterpret_cast<uint32_t*>(out)[i] = pack4(g0, g1, g2, g3);
         } else {
@@ -105,8 +109,11 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     const bool aligned = ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) &&
                          ((reinterpret_cast<uintptr_t>(d_out) & (one_channel ? 3u : 15u)) == 0);
     const size_t nquads = aligned ? npx / 4 : 0;
-    // 256 CUs x 8 resident blocks; grid-stride the rest (guide: cap ~2048 blocks for streaming)
-    constexpr unsigned kCap = 256 * 8;
+    // grid-stride; measured on MI355X (tools/membench.hip): a flat 16 B/lane stream runs 5.3 TB/s with
+    // 2,048 blocks, 6.2-6.4 TB/s with >= 8k blocks and non-temporal loads + stores; this kernel: 4.8 / 5.6 / 5.9 TB/s at 2k / 8k / 64k blocks
+    unsigned kCap = 65536;
+    if (const char* e = getenv("MI355_TUNE_GRAY_BLOCKS"))  // tuning experiments only
+        kCap = atoi(e) > 0 ? (unsigned)atoi(e) : kCap;
     if (nquads) {
         const unsigned grid = grid_for(nquads, kGrayThreads * kGrayIlp, kCap);
         if (one_channel)

@@ -200,7 +200,8 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     const int quads = w / 4;
     const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
     const int lanes_out = (quads + nstrips - 1) / nstrips;
-    int band_rows = 64;
+    // 2R+2 warm-up rows per band are pure overhead for this VALU-heavy kernel: 128-row bands (measured)
+    int band_rows = 128;
     if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
         band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
     if (h < band_rows)

@@ -41,7 +41,7 @@ for f in find("pmc*/**/*counter_collection.csv"):
     for r in rows:
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, cs in agg.items():
-        if "gauss" in k or "sobel" in k or "gray" in k or "pipeline" in k:
+        if any(t in k for t in ("gauss", "sobel", "gray", "pipe_")):
             for c, v in cs.items():
                 print("%-60s %-24s n=%3d mean=%.6g" % (k[:60], c, len(v), sum(v) / len(v)))
 
@@ -54,7 +54,7 @@ kname = None
 for f in find("pmc*/**/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if any(t in k for t in ("gauss", "sobel", "gray", "pipeline")):
+        if any(t in k for t in ("gauss", "sobel", "gray", "pipe_")):
             kname = k
             if r["Counter_Name"] == "FETCH_SIZE":
                 fetch = (fetch or []) + [float(r["Counter_Value"])]
