@@ -36,13 +36,16 @@ FILTER_ID = {"gray": 0, "gray1": 1, "gauss": 2, "sobel": 3, "pipeline": 4}
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    # defaults: 60 launches x ~3 ms.  The chip needs some tens of ms of continuous work to settle its clocks
+    # (measured: the same kernel reads 4.6 TB/s over a 19 ms run and 5.2-5.4 TB/s over 50-800 ms runs)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=10)
     p.add_argument("--filter", default="gauss", choices=sorted(FILTER_ID))
     p.add_argument("--width", type=int, default=3840)
     p.add_argument("--height", type=int, default=2160)
-    p.add_argument("--frames", type=int, default=64, help="frames per GPU per step (>=32: working set "
-                   "must exceed the 256 MiB Infinity Cache so the kernel streams from HBM)")
+    p.add_argument("--frames", type=int, default=256, help="frames per GPU per step (>=32: working set must "
+                   "exceed the 256 MiB Infinity Cache so the kernel streams from HBM; 256 x 4K = 8.5 GB in + "
+                   "8.5 GB out of the 288 GB)")
     p.add_argument("--k", type=int, default=5)
     p.add_argument("--sigma", type=float, default=1.5)
     p.add_argument("--mode", default="fast", choices=["fast", "exact"])
@@ -50,6 +53,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
+    p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
+                   "many frames (>= --frames) but process only --frames of them")
     return p.parse_args()
 
 
@@ -124,8 +129,9 @@ def main():
     w, h, F = args.width, args.height, args.frames
     filt = FILTER_ID[args.filter]
     out_bpp = pkg.imgfilter.OUT_BPP[filt]
-    d_in = torch.empty((F, h, w, 4), dtype=torch.uint8, device=dev)
-    d_out = torch.empty((F, h, w, out_bpp), dtype=torch.uint8, device=dev)
+    FA = max(F, args.alloc_frames)
+    d_in = torch.empty((FA, h, w, 4), dtype=torch.uint8, device=dev)[:F]
+    d_out = torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev)[:F]
     first_frame = rank * F
     ctx.synth_dev(d_in.data_ptr(), w, h, F, first_frame=first_frame, seed=0x5EED, mode=args.synth_mode)
 

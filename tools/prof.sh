@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 # the trace pass runs bench.py's DEFAULT step/warmup counts so its per-kernel average can be laid beside
 # bench.py's own HIP-event figure; the counter passes use fewer steps (counters serialise dispatches)
 TRACE_ARGS="--no-cpu-baseline --no-ceiling $*"
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --no-ceiling $*"
+ARGS="--steps 5 --warmup 2 --no-cpu-baseline --no-ceiling $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $TRACE_ARGS > $OUT/trace.log 2>&1
 echo "trace rc=$?" >> $OUT/trace.log
 i=0
