@@ -24,56 +24,18 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "slide_common.hpp"
 
 namespace mi355 {
 
 namespace {
 
-constexpr int kLanesOutMax = 62;  // 64 lanes minus one halo lane per side
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = kSlideWavesPerBlock;
 
 template <int K>
 struct Weights {
     float w[K];
 };
-
-// Rows [0, y_split) of every frame are cut into nbands_a bands of rows_a rows (phase A, dispatched first);
-// rows [y_split, h) into nbands_b bands of rows_b rows (phase B, dispatched last).
-struct BandPlan {
-    int rows_a, nbands_a, rows_b, nbands_b, y_split;
-    uint32_t nwork_a, nwork_b, nblocks_a, nblocks_b;
-};
-
-// resident = waves the chip holds at once for this kernel (CUs x 4 SIMDs x waves/SIMD)
-inline BandPlan make_band_plan(int h, int nstrips, int nframes, int rows_big, int rows_small, double tail_frac)
-{
-    BandPlan p{};
-    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
-        rows_big = atoi(e) > 0 ? atoi(e) : rows_big;
-    if (const char* e = getenv("MI355_TUNE_TAIL_ROWS"))
-        rows_small = atoi(e) > 0 ? atoi(e) : rows_small;
-    if (const char* e = getenv("MI355_TUNE_TAIL_FRAC"))
-        tail_frac = atof(e);
-    int h_b = (int)(h * tail_frac);
-    if (h_b < rows_small || h - h_b < rows_big || tail_frac <= 0.0)
-        h_b = 0;  // small images: one phase
-    const int h_a = h - h_b;
-    p.nbands_a = (h_a + rows_big - 1) / rows_big;
-    p.rows_a = (h_a + p.nbands_a - 1) / p.nbands_a;  // balance
-    p.y_split = h_a;
-    if (h_b > 0) {
-        p.nbands_b = (h_b + rows_small - 1) / rows_small;
-        p.rows_b = (h_b + p.nbands_b - 1) / p.nbands_b;
-    } else {
-        p.nbands_b = 0;
-        p.rows_b = 1;
-    }
-    p.nwork_a = (uint32_t)((size_t)nstrips * p.nbands_a * nframes);
-    p.nwork_b = (uint32_t)((size_t)nstrips * p.nbands_b * nframes);
-    p.nblocks_a = (p.nwork_a + kWavesPerBlock - 1) / kWavesPerBlock;
-    p.nblocks_b = (p.nwork_b + kWavesPerBlock - 1) / kWavesPerBlock;
-    return p;
-}
 
 __device__ __forceinline__ float dpp_from_left(float v)
 {
@@ -197,22 +159,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
 {
     constexpr int K = 2 * R + 1;
     const int lane = threadIdx.x & 63;
-    // Two phases of work items (BandPlan): tall bands first, short bands last, so that the final,
-    // partially filled round of resident waves is made of short items.  Blocks are dispatched in
-    // blockIdx order; within a phase the XCD remap keeps neighbouring strips/bands on one L2.
-    // Everything derived from `work` is wave-uniform: keep it in SGPRs.
-    const bool tail = blockIdx.x >= plan.nblocks_a;
-    const uint32_t blk = tail ? xcd_remap(blockIdx.x - plan.nblocks_a, plan.nblocks_b)
-                              : xcd_remap(blockIdx.x, plan.nblocks_a);
-    const uint32_t work =
-        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
-    if (work >= (tail ? plan.nwork_b : plan.nwork_a))
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
         return;
-    const int nbands = tail ? plan.nbands_b : plan.nbands_a;
-    const int band_rows = tail ? plan.rows_b : plan.rows_a;
-    const int strip = work % nstrips;
-    const int band = (work / nstrips) % nbands;
-    const size_t frame = work / ((uint32_t)nstrips * nbands);
+    const int strip = it.strip, y0 = it.y0, nout = it.nout;
+    const size_t frame = it.frame;
 
     const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
     const int q_load = clampi(q_lane, 0, quads - 1);   // replicated at the image border
@@ -221,8 +172,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
 
-    const int y0 = (tail ? plan.y_split : 0) + band * band_rows;
-    const int nout = min(band_rows, (tail ? h : plan.y_split) - y0);
     const int nin = nout + 2 * R;
 
     const size_t row_bytes = (size_t)quads * 16;
@@ -343,14 +292,12 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
                     const GaussCoef& coef)
 {
     constexpr int K = 2 * R + 1;
-    const int quads = w / 4;
-    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
-    const int lanes_out = (quads + nstrips - 1) / nstrips;
-    // bands: ~128 rows amortise the 2R warm-up rows to a few percent; the last ~20 % of every frame is cut
-    // into ~40-row bands that are dispatched after all tall bands (see BandPlan)
-    if ((size_t)nstrips * ((h + 31) / 32) * (size_t)nframes > 0x7FFFFFFFull)
+    const StripPlan sp = make_strip_plan(w);
+    const int quads = sp.quads, nstrips = sp.nstrips, lanes_out = sp.lanes_out;
+    // 116 VGPRs at k = 5 -> 4 waves/SIMD; 3 at k = 7, 2 at k = 9
+    BandPlan plan;
+    if (!make_band_plan(h, nstrips, nframes, K <= 5 ? 4 : (K == 7 ? 3 : 2), 96, 270, 40, 0.1, &plan))
         return hipErrorInvalidValue;
-    const BandPlan plan = make_band_plan(h, nstrips, nframes, 128, 40, 0.2);
     Weights<K> wts;
     for (int j = 0; j < K; j++)
         wts.w[j] = coef.h_w1d[j];

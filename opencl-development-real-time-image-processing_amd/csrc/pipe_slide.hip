@@ -22,13 +22,13 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "slide_common.hpp"
 
 namespace mi355 {
 
 namespace {
 
-constexpr int kLanesOutMax = 62;
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = kSlideWavesPerBlock;
 
 template <int K>
 struct PWeights {
@@ -50,7 +50,7 @@ __device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
 template <int R, bool CLAMP>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
-    int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks, PWeights<2 * R + 1> wts)
+    int lanes_out, BandPlan plan, PWeights<2 * R + 1> wts)
 {
     constexpr int K = 2 * R + 1;
     __shared__ uint8_t lut[256];  // lut[b] = luma(b, b, b), the reference double-precision formula
@@ -58,14 +58,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
-    const uint32_t work =
-        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
-    if (work >= nwork)
-        return;  // after the only barrier
-    const int strip = work % nstrips;
-    const int band = (work / nstrips) % nbands;
-    const size_t frame = work / ((uint32_t)nstrips * nbands);
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
+        return;  // (pipeline: after the only barrier)
+    const int strip = it.strip, y0 = it.y0, nout = it.nout;
+    const size_t frame = it.frame;
 
     const int q_lane = strip * lanes_out + lane - 1;
     const int q_load = clampi(q_lane, 0, quads - 1);
@@ -74,8 +71,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
 
-    const int y0 = band * band_rows;
-    const int nout = min(band_rows, h - y0);
     // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R
     const int nin = nout + 2 + 2 * R;
 
@@ -197,20 +192,10 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
                     const GaussCoef& coef)
 {
     constexpr int K = 2 * R + 1;
-    const int quads = w / 4;
-    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
-    const int lanes_out = (quads + nstrips - 1) / nstrips;
-    // 2R+2 warm-up rows per band are pure overhead for this VALU-heavy kernel: 128-row bands (measured)
-    int band_rows = 128;
-    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
-        band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
-    if (h < band_rows)
-        band_rows = h;
-    const int nbands = (h + band_rows - 1) / band_rows;
-    band_rows = (h + nbands - 1) / nbands;
-    const size_t nwork = (size_t)nstrips * nbands * nframes;
-    const size_t nblocks = (nwork + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (nblocks > 0x7FFFFFFFull)
+    const StripPlan sp = make_strip_plan(w);
+    // ~60 VGPRs -> 8 waves/SIMD; 2R+2 warm-up rows per band are pure overhead for this VALU-heavy kernel
+    BandPlan plan;
+    if (!make_band_plan(h, sp.nstrips, nframes, 8, 64, 270, 32, 0.1, &plan))
         return hipErrorInvalidValue;
     PWeights<K> wts;
     double wsum = 0.0;
@@ -220,13 +205,11 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     }
     const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);
     if (clamp)
-        hipLaunchKernelGGL((pipe_slide_kernel<R, true>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork,
-                           (uint32_t)nblocks, wts);
+        hipLaunchKernelGGL((pipe_slide_kernel<R, true>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan, wts);
     else
-        hipLaunchKernelGGL((pipe_slide_kernel<R, false>), dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork,
-                           (uint32_t)nblocks, wts);
+        hipLaunchKernelGGL((pipe_slide_kernel<R, false>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan, wts);
     return hipGetLastError();
 }
 

@@ -1,0 +1,112 @@
+// slide_common.hpp — work decomposition shared by the register-resident sliding-window kernels
+// (gauss_slide.hip, sobel_slide.hip, pipe_slide.hip).
+//
+// A work item is one wave walking one (frame, band of rows, strip of <= 62 lanes + 2 halo lanes).
+// Band height trades two costs measured on MI355X:
+//   * every band re-reads (and, for the Gaussian stages, re-computes) its warm-up rows, so tall bands are
+//     cheaper per pixel;
+//   * a launch should hold roughly ten "rounds" of resident waves, otherwise ramp-up and the last, partly
+//     filled round show (64 x 4K frames in 128-row bands are only 4.25 rounds).
+// So the height adapts to the batch: rows = frame rows x strips x frames / (10 x resident waves), clamped
+// to [rows_min, rows_max].  In addition the last ~10 % of every frame is cut into short bands that are
+// dispatched after all tall ones (blocks start in blockIdx order), so the tail of the launch is made of
+// short items (+6 % on 64-frame batches at steady clocks).
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+
+#include "common.hpp"
+
+namespace mi355 {
+
+constexpr int kSlideLanesOutMax = 62;  // 64 lanes minus one halo lane per side
+constexpr int kSlideWavesPerBlock = 4;
+
+// Rows [0, y_split) of every frame: nbands_a bands of rows_a rows (phase A, dispatched first);
+// rows [y_split, h): nbands_b bands of rows_b rows (phase B, dispatched last).
+struct BandPlan {
+    int rows_a, nbands_a, rows_b, nbands_b, y_split;
+    uint32_t nwork_a, nwork_b, nblocks_a, nblocks_b;
+};
+
+struct StripPlan {
+    int quads, nstrips, lanes_out;
+};
+
+inline StripPlan make_strip_plan(int w)
+{
+    StripPlan s;
+    s.quads = w / 4;
+    s.nstrips = (s.quads + kSlideLanesOutMax - 1) / kSlideLanesOutMax;
+    s.lanes_out = (s.quads + s.nstrips - 1) / s.nstrips;  // e.g. 4K: 960 quads = 16 strips x 60 lanes
+    return s;
+}
+
+// waves_per_simd: occupancy of the kernel (from its VGPR count); rows_min/rows_max: clamp of the tall bands
+inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, int rows_min, int rows_max,
+                           int rows_tail, double tail_frac, BandPlan* out)
+{
+    const double resident = 256.0 * 4.0 * waves_per_simd;
+    double rows = (double)h * nstrips * nframes / (10.0 * resident);
+    int rows_big = (int)(rows < rows_min ? rows_min : (rows > rows_max ? rows_max : rows));
+    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
+        rows_big = atoi(e) > 0 ? atoi(e) : rows_big;
+    if (const char* e = getenv("MI355_TUNE_TAIL_ROWS"))
+        rows_tail = atoi(e) > 0 ? atoi(e) : rows_tail;
+    if (const char* e = getenv("MI355_TUNE_TAIL_FRAC"))
+        tail_frac = atof(e);
+    BandPlan p{};
+    int h_b = (int)(h * tail_frac);
+    if (h_b < rows_tail || h - h_b < rows_big || tail_frac <= 0.0 || rows_tail >= rows_big)
+        h_b = 0;  // small images: one phase
+    const int h_a = h - h_b;
+    p.nbands_a = (h_a + rows_big - 1) / rows_big;
+    p.rows_a = (h_a + p.nbands_a - 1) / p.nbands_a;  // balance the bands
+    p.y_split = h_a;
+    if (h_b > 0) {
+        p.nbands_b = (h_b + rows_tail - 1) / rows_tail;
+        p.rows_b = (h_b + p.nbands_b - 1) / p.nbands_b;
+    } else {
+        p.nbands_b = 0;
+        p.rows_b = 1;
+    }
+    const size_t na = (size_t)nstrips * p.nbands_a * nframes, nb = (size_t)nstrips * p.nbands_b * nframes;
+    if (na + nb > 0x3FFFFFFFull)
+        return false;
+    p.nwork_a = (uint32_t)na;
+    p.nwork_b = (uint32_t)nb;
+    p.nblocks_a = (p.nwork_a + kSlideWavesPerBlock - 1) / kSlideWavesPerBlock;
+    p.nblocks_b = (p.nwork_b + kSlideWavesPerBlock - 1) / kSlideWavesPerBlock;
+    *out = p;
+    return true;
+}
+
+#ifdef __HIPCC__
+// What every sliding kernel starts with: which (frame, band, strip) this wave owns.  Wave-uniform
+// (readfirstlane keeps it in SGPRs).  Returns false for the padding waves of the last block of a phase.
+struct SlideItem {
+    int strip, y0, nout;
+    size_t frame;
+};
+
+__device__ __forceinline__ bool slide_item(const BandPlan& plan, int nstrips, int h, SlideItem* it)
+{
+    const bool tail = blockIdx.x >= plan.nblocks_a;
+    const uint32_t blk = tail ? xcd_remap(blockIdx.x - plan.nblocks_a, plan.nblocks_b)
+                              : xcd_remap(blockIdx.x, plan.nblocks_a);
+    const uint32_t work =
+        __builtin_amdgcn_readfirstlane(blk * kSlideWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
+    if (work >= (tail ? plan.nwork_b : plan.nwork_a))
+        return false;
+    const int nbands = tail ? plan.nbands_b : plan.nbands_a;
+    const int band_rows = tail ? plan.rows_b : plan.rows_a;
+    it->strip = work % nstrips;
+    const int band = (work / nstrips) % nbands;
+    it->frame = work / ((uint32_t)nstrips * nbands);
+    it->y0 = (tail ? plan.y_split : 0) + band * band_rows;
+    it->nout = min(band_rows, (tail ? h : plan.y_split) - it->y0);
+    return true;
+}
+#endif
+
+}  // namespace mi355

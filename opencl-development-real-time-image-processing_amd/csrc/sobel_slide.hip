@@ -21,13 +21,13 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "slide_common.hpp"
 
 namespace mi355 {
 
 namespace {
 
-constexpr int kLanesOutMax = 62;
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = kSlideWavesPerBlock;
 
 __device__ __forceinline__ float dpp_left(float v)  // lane l <- lane l-1
 {
@@ -43,18 +43,15 @@ __device__ __forceinline__ float dpp_right(float v)  // lane l <- lane l+1
 
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
-    int lanes_out, int band_rows, int nbands, uint32_t nwork, uint32_t nblocks)
+    int lanes_out, BandPlan plan)
 {
     constexpr int K = 3;
     const int lane = threadIdx.x & 63;
-    const uint32_t blk = xcd_remap(blockIdx.x, nblocks);
-    const uint32_t work =
-        __builtin_amdgcn_readfirstlane(blk * kWavesPerBlock + (uint32_t)(threadIdx.x >> 6));
-    if (work >= nwork)
-        return;
-    const int strip = work % nstrips;
-    const int band = (work / nstrips) % nbands;
-    const size_t frame = work / ((uint32_t)nstrips * nbands);
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
+        return;  // (pipeline: after the only barrier)
+    const int strip = it.strip, y0 = it.y0, nout = it.nout;
+    const size_t frame = it.frame;
 
     const int q_lane = strip * lanes_out + lane - 1;
     const int q_load = clampi(q_lane, 0, quads - 1);
@@ -63,8 +60,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
 
-    const int y0 = band * band_rows;
-    const int nout = min(band_rows, h - y0);
     const int nin = nout + 2;
 
     const size_t row_bytes = (size_t)quads * 16;
@@ -145,24 +140,15 @@ bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
 
 hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes)
 {
-    const int quads = w / 4;
-    const int nstrips = (quads + kLanesOutMax - 1) / kLanesOutMax;
-    const int lanes_out = (quads + nstrips - 1) / nstrips;
-    // 32-row bands: this kernel is light (50 VGPRs, 8 waves/SIMD), so short work items matter more than
-    // the 2/32 halo-row re-reads (measured: 4.49 TB/s at 32 rows vs 4.04 at 128 on 64 x 4K frames)
-    int band_rows = 32;
-    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
-        band_rows = atoi(e) > 0 ? atoi(e) : band_rows;
-    if (h < band_rows)
-        band_rows = h;
-    const int nbands = (h + band_rows - 1) / band_rows;
-    band_rows = (h + nbands - 1) / nbands;
-    const size_t nwork = (size_t)nstrips * nbands * nframes;
-    const size_t nblocks = (nwork + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (nblocks > 0x7FFFFFFFull)
+    const StripPlan sp = make_strip_plan(w);
+    // 50 VGPRs -> 8 waves/SIMD, and only 2 warm-up rows per band (loads that hit L2): this light kernel
+    // wants many short work items — measured at steady clocks on 256 x 4K frames: 16-row bands 5.2 TB/s,
+    // 32 rows 5.0, 64 rows 4.5, 128 rows 4.2
+    BandPlan plan;
+    if (!make_band_plan(h, sp.nstrips, nframes, 8, 16, 16, 16, 0.0, &plan))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sobel_slide_kernel, dim3((unsigned)nblocks), dim3(kWavesPerBlock * 64), 0, stream, d_in,
-                       d_out, quads, h, nstrips, lanes_out, band_rows, nbands, (uint32_t)nwork, (uint32_t)nblocks);
+    hipLaunchKernelGGL(sobel_slide_kernel, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0, stream,
+                       d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan);
     return hipGetLastError();
 }
 
