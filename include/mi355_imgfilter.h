@@ -131,6 +131,19 @@ int mi355_filter_batched(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_
 /* bytes per output pixel of a filter (4 or 1), or MI355_ERR_BAD_ARG */
 int mi355_filter_out_bpp(int filter);
 
+/* Streamed host-buffer form: nframes frames in `rgba` -> `out`, both on the host, moved
+ * in chunks of chunk_frames (0 = choose) through three device slots with three stages in flight on three HIP
+ * streams — H2D of chunk i+1, the kernel of chunk i, D2H of chunk i-1 — instead of the reference's
+ * write / wait / kernel / wait / read / wait per frame (RT/src/Controller.cpp:470,488,512).  Results are
+ * identical to mi355_filter_batched.  Any host memory works; the copies run at PCIe DMA rate and overlap in
+ * both directions only when `rgba` and `out` are pinned (mi355_host_alloc).  elapsed_ms (may be NULL)
+ * receives the wall time of the whole call, PCIe included. */
+int mi355_filter_stream(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h,
+                        int nframes, int chunk_frames, int k, float sigma, double* elapsed_ms);
+/* Pinned (page-locked) host memory for frames: hipHostMalloc / hipHostFree. */
+int mi355_host_alloc(mi355_ctx* ctx, size_t nbytes, void** h_ptr);
+int mi355_host_free(mi355_ctx* ctx, void* h_ptr);
+
 /* ---- device-resident calls -----------------------------------------------------------------
  * d_in / d_out are device pointers on the context's GPU holding nframes tightly packed frames;
  * the call enqueues the kernel(s) on the context's stream and returns without synchronising.

@@ -38,6 +38,13 @@ struct mi355_ctx {
     void* d_out = nullptr;
     size_t d_out_cap = 0;
     unsigned long long* d_acc = nullptr;
+    // streamed path: copy streams, per-slot events and device slots (created on first use)
+    static constexpr int kSlots = 3;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_h2d[kSlots] = {}, ev_k[kSlots] = {}, ev_d2h[kSlots] = {};
+    void* slot_in[kSlots] = {};
+    void* slot_out[kSlots] = {};
+    size_t slot_in_cap = 0, slot_out_cap = 0;
     int gauss_mode = MI355_GAUSS_FAST;
     int gauss_impl = MI355_GAUSS_IMPL_AUTO;
     int last_hip = 0;
@@ -369,6 +376,22 @@ MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
         (void)hipFree(ctx->d_out);
     if (ctx->d_acc)
         (void)hipFree(ctx->d_acc);
+    for (int i = 0; i < mi355_ctx::kSlots; i++) {
+        if (ctx->slot_in[i])
+            (void)hipFree(ctx->slot_in[i]);
+        if (ctx->slot_out[i])
+            (void)hipFree(ctx->slot_out[i]);
+        if (ctx->ev_h2d[i])
+            (void)hipEventDestroy(ctx->ev_h2d[i]);
+        if (ctx->ev_k[i])
+            (void)hipEventDestroy(ctx->ev_k[i]);
+        if (ctx->ev_d2h[i])
+            (void)hipEventDestroy(ctx->ev_d2h[i]);
+    }
+    if (ctx->s_h2d)
+        (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h)
+        (void)hipStreamDestroy(ctx->s_d2h);
     for (auto& ev : ctx->ev)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -493,6 +516,123 @@ MI355_API int mi355_filter_batched(mi355_ctx* ctx, int filter, const uint8_t* rg
                                    int h, int nframes, int k, float sigma, uint64_t prof_ns[6])
 {
     return run_host(ctx, filter, rgba, out, w, h, nframes, k, sigma, prof_ns);
+}
+
+MI355_API int mi355_host_alloc(mi355_ctx* ctx, size_t nbytes, void** h_ptr)
+{
+    if (!ctx || !h_ptr || nbytes == 0)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipHostMalloc(h_ptr, nbytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        ctx->last_hip = (int)e;
+        *h_ptr = nullptr;
+        return MI355_ERR_NOMEM;
+    }
+    return MI355_OK;
+}
+
+MI355_API int mi355_host_free(mi355_ctx* ctx, void* h_ptr)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    if (h_ptr)
+        HIP_TRY(ctx, hipHostFree(h_ptr));
+    return MI355_OK;
+}
+
+MI355_API int mi355_filter_stream(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h,
+                                  int nframes, int chunk_frames, int k, float sigma, double* elapsed_ms)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    const int bpp = mi355_filter_out_bpp(filter);
+    if (bpp < 0 || chunk_frames < 0)
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(rgba, out, w, h, nframes);
+    if (rc != MI355_OK)
+        return rc;
+    if (filter_needs_gauss(filter) && (!valid_k(k) || !valid_sigma(sigma)))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t fpx = (size_t)w * h;
+    if (chunk_frames == 0) {
+        // ~64 MB of input per chunk: long enough DMA transfers to run at link rate, short enough to overlap
+        chunk_frames = (int)((64u << 20) / (fpx * 4));
+        if (chunk_frames < 1)
+            chunk_frames = 1;
+    }
+    if (chunk_frames > nframes)
+        chunk_frames = nframes;
+    constexpr int NS = mi355_ctx::kSlots;
+    if (!ctx->s_h2d) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < NS; i++) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_h2d[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_k[i], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming));
+        }
+    }
+    const size_t in_chunk = fpx * 4 * chunk_frames, out_chunk = fpx * (size_t)bpp * chunk_frames;
+    if (ctx->slot_in_cap < in_chunk || ctx->slot_out_cap < out_chunk) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        for (int i = 0; i < NS; i++) {
+            if (ctx->slot_in[i])
+                (void)hipFree(ctx->slot_in[i]);
+            if (ctx->slot_out[i])
+                (void)hipFree(ctx->slot_out[i]);
+            ctx->slot_in[i] = ctx->slot_out[i] = nullptr;
+        }
+        ctx->slot_in_cap = ctx->slot_out_cap = 0;
+        for (int i = 0; i < NS; i++) {
+            if (hipMalloc(&ctx->slot_in[i], in_chunk) != hipSuccess ||
+                hipMalloc(&ctx->slot_out[i], out_chunk) != hipSuccess)
+                return MI355_ERR_NOMEM;
+        }
+        ctx->slot_in_cap = in_chunk;
+        ctx->slot_out_cap = out_chunk;
+    }
+    if (filter_needs_gauss(filter)) {
+        const GaussCoef* coef = nullptr;
+        rc = get_coef(ctx, k, sigma, &coef);
+        if (rc != MI355_OK)
+            return rc;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t t0 = now_ns();
+    const int nchunks = (nframes + chunk_frames - 1) / chunk_frames;
+    for (int c = 0; c < nchunks; c++) {
+        const int slot = c % NS;
+        const int f0 = c * chunk_frames;
+        const int nf = (nframes - f0 < chunk_frames) ? nframes - f0 : chunk_frames;
+        // input slot is free once the kernel of chunk c-NS has read it
+        if (c >= NS)
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_h2d, ctx->ev_k[slot], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->slot_in[slot], rgba + (size_t)f0 * fpx * 4, fpx * 4 * nf,
+                                    hipMemcpyHostToDevice, ctx->s_h2d));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[slot], ctx->s_h2d));
+        // kernel: needs its input, and its output slot drained by the D2H of chunk c-NS
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[slot], 0));
+        if (c >= NS)
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[slot], 0));
+        rc = dispatch_dev(ctx, filter, ctx->slot_in[slot], ctx->slot_out[slot], w, h, nf, k, sigma);
+        if (rc != MI355_OK) {
+            (void)hipDeviceSynchronize();
+            return rc;
+        }
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_k[slot], ctx->stream));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_d2h, ctx->ev_k[slot], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(out + (size_t)f0 * fpx * bpp, ctx->slot_out[slot], fpx * (size_t)bpp * nf,
+                                    hipMemcpyDeviceToHost, ctx->s_d2h));
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_d2h[slot], ctx->s_d2h));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_d2h));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->s_h2d));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (elapsed_ms)
+        *elapsed_ms = (double)(now_ns() - t0) * 1e-6;
+    return MI355_OK;
 }
 
 MI355_API int mi355_filter_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int w, int h,

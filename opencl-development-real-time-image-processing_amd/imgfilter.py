@@ -83,6 +83,10 @@ def load_library():
         "mi355_pipeline_rgba8": [_vp, _u8p, _u8p, _ci, _ci, _ci, ctypes.c_float, _u64p],
         "mi355_filter_batched": [_vp, _ci, _u8p, _u8p, _ci, _ci, _ci, _ci, ctypes.c_float, _u64p],
         "mi355_filter_out_bpp": [_ci],
+        "mi355_filter_stream": [_vp, _ci, _u8p, _u8p, _ci, _ci, _ci, _ci, _ci, ctypes.c_float,
+                                ctypes.POINTER(ctypes.c_double)],
+        "mi355_host_alloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
+        "mi355_host_free": [_vp, _vp],
         "mi355_gray_rgba8_dev": [_vp, _vp, _vp, _ci, _ci, _ci],
         "mi355_gray1_rgba8_dev": [_vp, _vp, _vp, _ci, _ci, _ci],
         "mi355_gauss_rgba8_dev": [_vp, _vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_float],
@@ -226,6 +230,35 @@ class Context:
 
     def pipeline(self, rgba, k, sigma, profile=False):
         return self._host(FILTER_PIPELINE, rgba, k, sigma, profile=profile)
+
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array over pinned host memory (mi355_host_alloc); release with pinned_free(arr)."""
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = _vp()
+        _check("mi355_host_alloc", self._lib.mi355_host_alloc(self._h, nbytes, ctypes.byref(p)), self._h)
+        buf = (ctypes.c_uint8 * nbytes).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def pinned_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            _check("mi355_host_free", self._lib.mi355_host_free(self._h, _vp(p)), self._h)
+
+    def stream(self, filt, frames, out=None, k=0, sigma=0.0, chunk_frames=0):
+        """mi355_filter_stream: overlapped H2D / kernel / D2H over a host batch.  Returns (out, elapsed_ms)."""
+        assert frames.flags["C_CONTIGUOUS"] and frames.dtype == np.uint8 and frames.ndim == 4
+        n, h, w, _ = frames.shape
+        bpp = OUT_BPP[filt]
+        if out is None:
+            out = np.empty((n, h, w, 4) if bpp == 4 else (n, h, w), np.uint8)
+        ms = ctypes.c_double(0)
+        rc = self._lib.mi355_filter_stream(self._h, int(filt), frames.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p),
+                                           w, h, n, int(chunk_frames), int(k), float(sigma), ctypes.byref(ms))
+        _check("mi355_filter_stream", rc, self._h)
+        return out, ms.value
 
     def single(self, name, rgba, *args):
         """The per-frame C entry points themselves (mi355_gray_rgba8, ...), one frame."""

@@ -222,6 +222,25 @@ def test_batched_equals_per_frame(ctx, oracle):
         assert np.array_equal(p[f], ctx.pipeline(frames[f], 5, 1.5))
 
 
+def test_streamed_host_path_equals_batched(ctx, pkg, oracle):
+    """mi355_filter_stream (pinned or pageable host memory, several chunks, ragged last chunk)."""
+    frames = oracle.synth_rgba(320, 90, 11, first_frame=1, mode=1)
+    for filt, name, args in ((pkg.FILTER_GAUSS, "gauss", (5, 1.5)), (pkg.FILTER_SOBEL, "sobel", ()),
+                             (pkg.FILTER_PIPELINE, "pipeline", (5, 1.5)), (pkg.FILTER_GRAY, "gray", ())):
+        want = getattr(ctx, name)(frames, *args)
+        k, sigma = args if args else (0, 0.0)
+        for chunk in (1, 4, 0):
+            got, ms = ctx.stream(filt, frames, k=k, sigma=sigma, chunk_frames=chunk)
+            assert np.array_equal(got, want) and ms > 0
+    pin_in = ctx.pinned_empty(frames.shape)
+    pin_out = ctx.pinned_empty(frames.shape)
+    pin_in[...] = frames
+    got, _ = ctx.stream(pkg.FILTER_GAUSS, pin_in, out=pin_out, k=5, sigma=1.5, chunk_frames=3)
+    assert np.array_equal(got, ctx.gauss(frames, 5, 1.5))
+    ctx.pinned_free(pin_in)
+    ctx.pinned_free(pin_out)
+
+
 def test_per_frame_entry_points_and_profiling_contract(ctx, oracle):
     """mi355_*_rgba8: six timestamps, write/kernel/read, non-decreasing (Controller.cpp:66-74)."""
     img = rand_rgba(64, 96, seed=4)
