@@ -68,9 +68,9 @@ int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
  *   AUTO — the register-resident sliding-window kernels when they apply (width % 4 == 0, 16-byte aligned
  *          buffers; Gaussian additionally k in {3,5,7,9} and FAST mode); the LDS-tiled kernels otherwise.
  *   TILE — always the LDS-tiled kernels. */
-#define MI355_GAUSS_IMPL_AUTO 0
-#define MI355_GAUSS_IMPL_TILE 1
-int mi355_ctx_set_gauss_impl(mi355_ctx* ctx, int impl);
+#define MI355_IMPL_AUTO 0
+#define MI355_IMPL_TILE 1
+int mi355_ctx_set_impl(mi355_ctx* ctx, int impl);
 
 /* ---- Gaussian coefficients -----------------------------------------------------------------
  * mi355_gauss_weights replaces Controller::_GenerateGaussianKernelBuffers

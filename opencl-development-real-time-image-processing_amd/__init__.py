@@ -12,8 +12,8 @@ from .imgfilter import (  # noqa: F401
     FILTER_SOBEL,
     GAUSS_EXACT,
     GAUSS_FAST,
-    GAUSS_IMPL_AUTO,
-    GAUSS_IMPL_TILE,
+    IMPL_AUTO,
+    IMPL_TILE,
     Context,
     Mi355Error,
     build_library,

@@ -46,7 +46,7 @@ struct mi355_ctx {
     void* slot_out[kSlots] = {};
     size_t slot_in_cap = 0, slot_out_cap = 0;
     int gauss_mode = MI355_GAUSS_FAST;
-    int gauss_impl = MI355_GAUSS_IMPL_AUTO;
+    int impl = MI355_IMPL_AUTO;
     int last_hip = 0;
     char name[256] = {};
     std::vector<CoefEntry> coefs;
@@ -228,13 +228,13 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
         e = launch_gray(ctx->stream, in, out, w, h, nframes, true);
         break;
     case MI355_FILTER_GAUSS:
-        e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->gauss_impl);
+        e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->impl);
         break;
     case MI355_FILTER_SOBEL:
-        e = launch_sobel(ctx->stream, in, out, w, h, nframes, ctx->gauss_impl);
+        e = launch_sobel(ctx->stream, in, out, w, h, nframes, ctx->impl);
         break;
     case MI355_FILTER_PIPELINE:
-        e = launch_pipeline(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->gauss_impl);
+        e = launch_pipeline(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->impl);
         break;
     default:
         return MI355_ERR_BAD_ARG;
@@ -444,11 +444,11 @@ MI355_API int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode)
     return MI355_OK;
 }
 
-MI355_API int mi355_ctx_set_gauss_impl(mi355_ctx* ctx, int impl)
+MI355_API int mi355_ctx_set_impl(mi355_ctx* ctx, int impl)
 {
-    if (!ctx || (impl != MI355_GAUSS_IMPL_AUTO && impl != MI355_GAUSS_IMPL_TILE))
+    if (!ctx || (impl != MI355_IMPL_AUTO && impl != MI355_IMPL_TILE))
         return MI355_ERR_BAD_ARG;
-    ctx->gauss_impl = impl;
+    ctx->impl = impl;
     return MI355_OK;
 }
 

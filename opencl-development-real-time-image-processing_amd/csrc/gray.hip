@@ -111,9 +111,10 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     const size_t nquads = aligned ? npx / 4 : 0;
     // grid-stride; measured on MI355X (tools/membench.hip): a flat 16 B/lane stream runs 5.3 TB/s with
     // 2,048 blocks, 6.2-6.4 TB/s with >= 8k blocks and non-temporal loads + stores; this kernel: 4.8 / 5.6 / 5.9 / 6.3 TB/s at 2k / 8k / 64k / 256k+ blocks
-    unsigned kCap = 1u << 20;
-    if (const char* e = getenv("MI355_TUNE_GRAY_BLOCKS"))  // tuning experiments only
-        kCap = atoi(e) > 0 ? (unsigned)atoi(e) : kCap;
+    static const unsigned kCap = [] {
+        const char* e = getenv("MI355_TUNE_GRAY_BLOCKS");  // tuning sweeps only
+        return (e && atoi(e) > 0) ? (unsigned)atoi(e) : (1u << 20);
+    }();
     if (nquads) {
         const unsigned grid = grid_for(nquads, kGrayThreads * kGrayIlp, kCap);
         if (one_channel)

@@ -49,12 +49,26 @@ inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, 
     const double resident = 256.0 * 4.0 * waves_per_simd;
     double rows = (double)h * nstrips * nframes / (10.0 * resident);
     int rows_big = (int)(rows < rows_min ? rows_min : (rows > rows_max ? rows_max : rows));
-    if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))  // tuning experiments only
-        rows_big = atoi(e) > 0 ? atoi(e) : rows_big;
-    if (const char* e = getenv("MI355_TUNE_TAIL_ROWS"))
-        rows_tail = atoi(e) > 0 ? atoi(e) : rows_tail;
-    if (const char* e = getenv("MI355_TUNE_TAIL_FRAC"))
-        tail_frac = atof(e);
+    // MI355_TUNE_* environment overrides exist for tuning sweeps only (tools/sweep*.sh); read once
+    static const struct Tune {
+        int band_rows = 0, tail_rows = 0;
+        double tail_frac = -1.0;
+        Tune()
+        {
+            if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))
+                band_rows = atoi(e);
+            if (const char* e = getenv("MI355_TUNE_TAIL_ROWS"))
+                tail_rows = atoi(e);
+            if (const char* e = getenv("MI355_TUNE_TAIL_FRAC"))
+                tail_frac = atof(e);
+        }
+    } tune;
+    if (tune.band_rows > 0)
+        rows_big = tune.band_rows;
+    if (tune.tail_rows > 0)
+        rows_tail = tune.tail_rows;
+    if (tune.tail_frac >= 0.0)
+        tail_frac = tune.tail_frac;
     BandPlan p{};
     int h_b = (int)(h * tail_frac);
     if (h_b < rows_tail || h - h_b < rows_big || tail_frac <= 0.0 || rows_tail >= rows_big)

@@ -21,7 +21,7 @@ _HEADER = os.path.join(_ROOT, "include", "mi355_imgfilter.h")
 
 FILTER_GRAY, FILTER_GRAY1, FILTER_GAUSS, FILTER_SOBEL, FILTER_PIPELINE = 0, 1, 2, 3, 4
 GAUSS_FAST, GAUSS_EXACT = 0, 1
-GAUSS_IMPL_AUTO, GAUSS_IMPL_TILE = 0, 1
+IMPL_AUTO, IMPL_TILE = 0, 1
 OUT_BPP = {FILTER_GRAY: 4, FILTER_GRAY1: 1, FILTER_GAUSS: 4, FILTER_SOBEL: 1, FILTER_PIPELINE: 1}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)
@@ -73,7 +73,7 @@ def load_library():
         "mi355_sync": [_vp],
         "mi355_last_hip_error": [_vp],
         "mi355_ctx_set_gauss_mode": [_vp, _ci],
-        "mi355_ctx_set_gauss_impl": [_vp, _ci],
+        "mi355_ctx_set_impl": [_vp, _ci],
         "mi355_gauss_weights": [_ci, ctypes.c_float, _f32p],
         "mi355_ctx_set_gauss_weights": [_vp, _ci, ctypes.c_float, _f32p],
         "mi355_gray_rgba8": [_vp, _u8p, _u8p, _ci, _ci, _u64p],
@@ -181,8 +181,8 @@ class Context:
     def set_gauss_mode(self, mode):
         _check("mi355_ctx_set_gauss_mode", self._lib.mi355_ctx_set_gauss_mode(self._h, int(mode)), self._h)
 
-    def set_gauss_impl(self, impl):
-        _check("mi355_ctx_set_gauss_impl", self._lib.mi355_ctx_set_gauss_impl(self._h, int(impl)), self._h)
+    def set_impl(self, impl):
+        _check("mi355_ctx_set_impl", self._lib.mi355_ctx_set_impl(self._h, int(impl)), self._h)
 
     def set_gauss_weights(self, k, sigma, table):
         table = np.ascontiguousarray(table, np.float32)

@@ -70,9 +70,9 @@ def test_gauss_sliding_window_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, si
     implement one canonical FAST arithmetic: identical bits.  Both are within 1 LSB of the CPU path."""
     img = rand_rgba(h, w, seed=h * 7 + w + k, alpha=None)
     ctx.set_gauss_mode(pkg.GAUSS_FAST)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    ctx.set_impl(pkg.IMPL_TILE)
     tiled = ctx.gauss(img, k, sigma)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    ctx.set_impl(pkg.IMPL_AUTO)
     slide = ctx.gauss(img, k, sigma)
     assert np.array_equal(slide, tiled)
     ref = oracle.gauss_rgba(img, k, sigma)
@@ -82,9 +82,9 @@ def test_gauss_sliding_window_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, si
 def test_gauss_sliding_window_batched_multi_band(ctx, pkg, oracle):
     """Several frames, several bands per frame (h > 128), several strips (w > 248), edge strips."""
     frames = oracle.synth_rgba(1000, 300, 3, first_frame=1, mode=1)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    ctx.set_impl(pkg.IMPL_TILE)
     tiled = ctx.gauss(frames, 5, 1.5)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    ctx.set_impl(pkg.IMPL_AUTO)
     slide = ctx.gauss(frames, 5, 1.5)
     assert np.array_equal(slide, tiled)
     ref = oracle.gauss_rgba(frames[2], 5, 1.5)
@@ -127,9 +127,9 @@ def test_sobel_sliding_window_kernel(ctx, pkg, oracle, h, w):
     """sobel_slide.hip (width % 4 == 0) against the oracle and against the LDS-tiled kernel."""
     for seed, mode in ((h + w, None), (7, 1)):
         img = rand_rgba(h, w, seed=seed) if mode is None else oracle.synth_rgba(w, h, 1, first_frame=seed, mode=1)[0]
-        ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+        ctx.set_impl(pkg.IMPL_TILE)
         tiled = ctx.sobel(img)
-        ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+        ctx.set_impl(pkg.IMPL_AUTO)
         slide = ctx.sobel(img)
         assert np.array_equal(slide, tiled)
         assert np.array_equal(slide, oracle.sobel_rgba(img))
@@ -177,10 +177,10 @@ def test_pipeline_sliding_window_kernel(ctx, pkg, oracle, k, sigma, h, w):
     chained; and it stays close to the CPU chain (the Gaussian stage may differ by 1 LSB before Sobel)."""
     img = oracle.synth_rgba(w, h, 1, first_frame=h + k, mode=(h + w) & 1)[0]
     ctx.set_gauss_mode(pkg.GAUSS_FAST)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    ctx.set_impl(pkg.IMPL_TILE)
     tiled = ctx.pipeline(img, k, sigma)
     chained_tiled = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    ctx.set_impl(pkg.IMPL_AUTO)
     slide = ctx.pipeline(img, k, sigma)
     chained = ctx.sobel(ctx.gauss(ctx.gray(img), k, sigma))
     assert np.array_equal(tiled, chained_tiled)
@@ -194,9 +194,9 @@ def test_pipeline_sliding_window_kernel(ctx, pkg, oracle, k, sigma, h, w):
 
 def test_pipeline_sliding_window_batched_multi_band(ctx, pkg, oracle):
     frames = oracle.synth_rgba(1000, 300, 3, first_frame=2, mode=1)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_TILE)
+    ctx.set_impl(pkg.IMPL_TILE)
     tiled = ctx.pipeline(frames, 5, 1.5)
-    ctx.set_gauss_impl(pkg.GAUSS_IMPL_AUTO)
+    ctx.set_impl(pkg.IMPL_AUTO)
     assert np.array_equal(ctx.pipeline(frames, 5, 1.5), tiled)
 
 
@@ -296,6 +296,34 @@ def test_bad_arguments_are_rejected_not_launched(ctx, pkg):
     with pytest.raises(pkg.Mi355Error):
         ctx.filter_dev(42, 16, 16, 8, 8, 1)
     assert np.array_equal(ctx.gray(img)[..., 3], np.full((8, 8), 255, np.uint8))   # still usable
+
+
+def test_random_shapes_all_kernels_agree(ctx, pkg, oracle):
+    """Seeded random (frames, h, w, k) shapes — band/strip/tail boundaries of the sliding-window work
+    decomposition are data dependent — every kernel pair must agree and match the oracle."""
+    rng = np.random.default_rng(20261004)
+    for case in range(36):
+        n = int(rng.integers(1, 4))
+        w = int(rng.integers(1, 130)) * 4 if case % 3 else int(rng.integers(1, 520))
+        h = int(rng.integers(1, 700)) if case % 4 else int(rng.integers(1, 40))
+        k = int(rng.choice([3, 5, 7, 9]))
+        sigma = float(rng.uniform(0.6, 3.0))
+        frames = oracle.synth_rgba(w, h, n, first_frame=case, seed=case + 1, mode=case & 1)
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        ctx.set_impl(pkg.IMPL_TILE)
+        g_t, s_t, p_t = ctx.gauss(frames, k, sigma), ctx.sobel(frames), ctx.pipeline(frames, k, sigma)
+        ctx.set_impl(pkg.IMPL_AUTO)
+        g_a, s_a, p_a = ctx.gauss(frames, k, sigma), ctx.sobel(frames), ctx.pipeline(frames, k, sigma)
+        tag = (case, n, h, w, k)
+        assert np.array_equal(g_a, g_t), tag
+        assert np.array_equal(s_a, s_t), tag
+        assert np.array_equal(p_a, p_t), tag
+        f = int(rng.integers(0, n))
+        assert np.array_equal(s_a[f], oracle.sobel_rgba(frames[f])), tag
+        assert np.array_equal(ctx.gray(frames)[f], oracle.gray_rgba(frames[f])), tag
+        if h * w <= 120000:
+            ref = oracle.gauss_rgba(frames[f], k, sigma)
+            assert np.abs(g_a[f].astype(np.int16) - ref.astype(np.int16)).max() <= 1, tag
 
 
 # ---- BASELINE.json full sizes: size-independent properties ------------------------------------
