@@ -56,13 +56,13 @@ __device__ __forceinline__ float luma_px_fast(uint32_t px)
 // integer fix-ups: with s = gx^2 + gy^2 (exact in fp32), round(sqrt(s)) = floor(0.5 + 0.5 * sqrt(4s - 1))
 // for s >= 1 — 4s-1 is never a perfect square and the argument of floor stays >= 1/511 away from an integer
 // for results <= 255, far more than the error of v_sqrt_f32.  Brute-forced against the exact integer form
-// for every s < 2^21, also with a +-2 ulp sqrt.  Returned as float in [0, 255].
-__device__ __forceinline__ float sobel_mag_fast(float gx, float gy)
+// for every s < 2^21, also with a +-2 ulp sqrt.  The float -> u32 conversion truncates, which is the floor.
+__device__ __forceinline__ uint32_t sobel_mag_fast(float gx, float gy)
 {
     const float s = __builtin_fmaf(gx, gx, gy * gy);
     const float t = fmaxf(__builtin_fmaf(4.0f, s, -1.0f), 0.0f);
     const float u = __builtin_amdgcn_sqrtf(t);
-    return fminf(__builtin_floorf(__builtin_fmaf(u, 0.5f, 0.5f)), 255.0f);
+    return (uint32_t)fminf(__builtin_fmaf(u, 0.5f, 0.5f), 255.5f);
 }
 
 __device__ __forceinline__ uint32_t gray_to_rgba(uint32_t g)

@@ -91,97 +91,110 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     };
 
     constexpr int PF = 3;
-    // one trip of the unrolled loop = LCM(K, 3) = 3K rows would be needed to make both rings static; instead
-    // the Sobel ring (3 rows) is rotated by register moves (12 v_mov per row) and only the K-ring is static
     u32x4 q[K];
 #pragma unroll
     for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
     float acc[K][4] = {};
-    float lt[4] = {}, lm[4] = {};  // l rows: top, middle (bottom is produced in the current step)
+    float l[3][4] = {};  // l rows of the last three blurred rows; slot = input row index % 3
 
-    for (int base = 0; base < nin; base += K) {
+    // One trip = 3K input rows, so that both rings (K vertical accumulators, 3 Sobel rows) have static slots:
+    // no register moves, no per-row selects.  K-row groups past the band's last input row are skipped.
+    for (int base = 0; base < nin; base += 3 * K) {
 #pragma unroll
-        for (int u = 0; u < K; u++) {
-            const int i = base + u;
-            u32x4 p = q[u];
-            q[(u + PF) % K] = load_row(i + PF);
-            if (edge_strip) {
-                if (left_of_image)
-                    p = u32x4{p.x, p.x, p.x, p.x};  // gray image clamps: replicate column 0
-                if (right_of_image)
-                    p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
-            }
-            float g[4];
+        for (int u3 = 0; u3 < 3; u3++) {
+            if (base + u3 * K < nin) {  // wave-uniform
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                g[j] = luma_px_fast(p[j]);
-            // vertical pass (canonical order): gray row i is tap j of blurred row i - j
+                for (int u = 0; u < K; u++) {
+                    const int i = base + u3 * K + u;
+                    const int s3 = (u3 * K + u) % 3;  // static after unrolling
+                    u32x4 p = q[u];
+                    q[(u + PF) % K] = load_row(i + PF);
+                    if (edge_strip) {
+                        if (left_of_image)
+                            p = u32x4{p.x, p.x, p.x, p.x};  // gray image clamps: replicate column 0
+                        if (right_of_image)
+                            p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
+                    }
+                    float g[4];
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                const int s = (u - j + K) % K;
+                    for (int j = 0; j < 4; j++)
+                        g[j] = luma_px_fast(p[j]);
+                    // vertical pass (canonical order): gray row i is tap j of blurred row i - j
 #pragma unroll
-                for (int e = 0; e < 4; e++)
-                    acc[s][e] = (j == 0) ? wv[0] * g[e] : __builtin_fmaf(wv[j], g[e], acc[s][e]);
-            }
-            const float* v = acc[(u + 1) % K];  // vertical sum of blurred row index rb = i - 2R (band-relative)
-            // horizontal pass (canonical order), neighbour-lane taps through DPP
-            float lb[4];
+                    for (int j = 0; j < K; j++) {
+                        const int s = (u - j + K) % K;
 #pragma unroll
-            for (int px = 0; px < 4; px++) {
-                float sum = 0.0f;
+                        for (int e = 0; e < 4; e++)
+                            acc[s][e] = (j == 0) ? wv[0] * g[e] : __builtin_fmaf(wv[j], g[e], acc[s][e]);
+                    }
+                    const float* v = acc[(u + 1) % K];  // vertical sum of the blurred row that just completed
+                    // horizontal pass (canonical order), neighbour-lane taps through DPP
+                    float* lb = l[s3];
 #pragma unroll
-                for (int t = 0; t < K; t++) {
-                    const int s = px - R + t;
-                    const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
-                    sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                    for (int px = 0; px < 4; px++) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int t = 0; t < K; t++) {
+                            const int s = px - R + t;
+                            const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
+                            sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                        }
+                        if constexpr (CLAMP)
+                            sum = fminf(sum, 255.0f);
+                        const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
+                        lb[px] = (float)lut[bq];            // luma(b,b,b) re-applied
+                    }
+                    if (edge_strip) {
+                        // the blurred image reflects (BORDER_REFLECT_101): x = -1 <- x = 1, x = w <- x = w-2
+                        const float from_right = dppr(lb[1]);  // lane+1's pixel 1
+                        const float from_left = dppl(lb[2]);   // lane-1's pixel 2
+                        if (left_of_image)
+                            lb[3] = from_right;
+                        if (right_of_image)
+                            lb[0] = from_left;
+                    }
+                    // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
+                    const int m = y0 - 2 + i - 2 * R;
+                    const float* lm = l[(s3 + 2) % 3];  // blurred row m
+                    const float* lt = l[(s3 + 1) % 3];  // blurred row m - 1
+                    // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the
+                    // bottom row (h) is row h-2 = the top row.  Wave-uniform and rare: a branch, not selects.
+                    const float* top = lt;
+                    const float* bot = lb;
+                    float cs[4], cd[4];
+                    if (__builtin_expect(m == 0 || m == h - 1, 0)) {
+                        // keeps this a real (never-taken) branch: hipcc otherwise if-converts both arms into
+                        // 8 v_cndmask per row on the common path
+                        asm volatile("; first / last image row");
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const float tv = (m == 0) ? lb[j] : lt[j];
+                            const float bv = (m == h - 1) ? lt[j] : lb[j];
+                            cs[j] = __builtin_fmaf(2.0f, lm[j], tv) + bv;
+                            cd[j] = bv - tv;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            cs[j] = __builtin_fmaf(2.0f, lm[j], top[j]) + bot[j];
+                            cd[j] = bot[j] - top[j];
+                        }
+                    }
+                    const float csl = dppl(cs[3]), csr = dppr(cs[0]);
+                    const float cdl = dppl(cd[3]), cdr = dppr(cd[0]);
+                    const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
+                    const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
+                    const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
+                    const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
+                    const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
+                    const uint32_t r = sobel_mag_fast(gx0, gy0) | (sobel_mag_fast(gx1, gy1) << 8) |
+                                       (sobel_mag_fast(gx2, gy2) << 16) | (sobel_mag_fast(gx3, gy3) << 24);
+                    if (stores && m >= y0 && m < y0 + nout)
+                        __builtin_nontemporal_store(
+                            r, reinterpret_cast<uint32_t*>(fout + (size_t)m * quads * 4 + out_off));
                 }
-                if constexpr (CLAMP)
-                    sum = fminf(sum, 255.0f);
-                const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
-                lb[px] = (float)lut[bq];            // luma(b,b,b) re-applied
-            }
-            if (edge_strip) {
-                // the blurred image reflects (BORDER_REFLECT_101): x = -1 <- x = 1, x = w <- x = w-2
-                const float from_right = dppr(lb[1]);  // lane+1's pixel 1
-                const float from_left = dppl(lb[2]);   // lane-1's pixel 2
-                if (left_of_image)
-                    lb[3] = from_right;
-                if (right_of_image)
-                    lb[0] = from_left;
-            }
-            // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
-            const int yb = y0 - 1 + i - 2 * R;
-            const int m = yb - 1;
-            // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the bottom
-            // row (h) is row h-2 = the top row.  (yb is wave-uniform.)
-            const bool first = (m == 0), last = (m == h - 1);
-            float cs[4], cd[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float top = first ? lb[j] : lt[j];
-                const float bot = last ? lt[j] : lb[j];
-                cs[j] = __builtin_fmaf(2.0f, lm[j], top) + bot;
-                cd[j] = bot - top;
-            }
-            const float csl = dppl(cs[3]), csr = dppr(cs[0]);
-            const float cdl = dppl(cd[3]), cdr = dppr(cd[0]);
-            const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
-            const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
-            const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
-            const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
-            const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
-            const uint32_t r = (uint32_t)sobel_mag_fast(gx0, gy0) | ((uint32_t)sobel_mag_fast(gx1, gy1) << 8) |
-                               ((uint32_t)sobel_mag_fast(gx2, gy2) << 16) |
-                               ((uint32_t)sobel_mag_fast(gx3, gy3) << 24);
-            if (stores && m >= y0 && m < y0 + nout)
-                __builtin_nontemporal_store(r,
-                                            reinterpret_cast<uint32_t*>(fout + (size_t)m * quads * 4 + out_off));
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                lt[j] = lm[j];
-                lm[j] = lb[j];
             }
         }
     }

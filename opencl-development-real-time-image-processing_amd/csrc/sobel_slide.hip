@@ -117,9 +117,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
             const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
             const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
             const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
-            const uint32_t r = (uint32_t)sobel_mag_fast(gx0, gy0) | ((uint32_t)sobel_mag_fast(gx1, gy1) << 8) |
-                               ((uint32_t)sobel_mag_fast(gx2, gy2) << 16) |
-                               ((uint32_t)sobel_mag_fast(gx3, gy3) << 24);
+            const uint32_t r = sobel_mag_fast(gx0, gy0) | (sobel_mag_fast(gx1, gy1) << 8) |
+                               (sobel_mag_fast(gx2, gy2) << 16) |
+                               (sobel_mag_fast(gx3, gy3) << 24);
             const int m = i - 2;
             if (stores && m >= 0 && m < nout)
                 __builtin_nontemporal_store(
