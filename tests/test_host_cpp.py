@@ -12,11 +12,12 @@ import __graft_entry__ as entry
 LIBDIR = os.path.join(entry.PKG_DIR, "lib")
 HOST_SO = os.path.join(LIBDIR, "libmi355_host.so")
 HOST_APP = os.path.join(LIBDIR, "host_app")
+HOST_ERRORS = os.path.join(LIBDIR, "host_errors")
 
 
 @pytest.fixture(scope="module")
 def host_built(pkg):
-    if not (os.path.exists(HOST_SO) and os.path.exists(HOST_APP)):
+    if not (os.path.exists(HOST_SO) and os.path.exists(HOST_APP) and os.path.exists(HOST_ERRORS)):
         subprocess.run(["make", "-s", "-j8", "-C", os.path.join(entry.PKG_DIR, "host")], check=True)
     return HOST_SO
 
@@ -93,3 +94,27 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
     assert prof.size == 12 and (np.diff(prof[:6].astype(np.int64)) >= 0).all() and prof[6] >= prof[5]
     rgba = np.dstack([crop, np.full(crop.shape[:2], 255, np.uint8)])
     assert np.array_equal(load(".ppm_gray", (96, 128, 4)), oracle.gray_rgba(rgba))
+
+
+def _run_err(what):
+    return subprocess.run([HOST_ERRORS, what], capture_output=True, text=True, timeout=120)
+
+
+def test_logger_throws_like_the_reference(host_built):
+    r = _run_err("log_throw")
+    assert r.returncode == 0 and "caught: Failed to open log file: /nonexistent-dir/x/y.log" in r.stdout
+
+
+@pytest.mark.gpu
+def test_error_conventions_match_the_reference(host_built):
+    """Exit codes and messages of the reference (SURVEY.md §8b "Error conventions")."""
+    r = _run_err("unknown_method")
+    assert r.returncode == 1 and "Unrecognised method" in r.stderr              # ProgramHandler.cpp:75-78
+    r = _run_err("bad_kernel")
+    assert r.returncode == 1 and "Error: clCreateKernel (-46)" in r.stderr      # Controller.cpp:5-11 (EXIT_FAILURE)
+    r = _run_err("bad_program")
+    assert r.returncode == 0 and "program is NULL" in r.stdout and "Failed to open file for reading: foo.cl" in r.stderr
+    r = _run_err("short_input")
+    assert r.returncode == 0 and "output untouched" in r.stdout and "[ERROR] Failed to write cl_mem" in r.stdout
+    r = _run_err("even_kernel")
+    assert r.returncode == 0 and "0 events" in r.stdout and "[ERROR] Failed when executing kernel: bad argument" in r.stdout
