@@ -11,6 +11,8 @@ hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
     // arithmetic for the small kernels and 4-pixel-aligned rows (every config in BASELINE.json).
     if (!exact && impl != 1 && gauss_slide_supported(d_in, d_out, w, h, coef.k))
         return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef);
+    if (!exact && impl != 1 && gauss_wide_supported(d_in, d_out, w, h, coef.k))
+        return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef);
     return launch_gauss_tile(stream, d_in, d_out, w, h, nframes, coef, exact);
 }
 

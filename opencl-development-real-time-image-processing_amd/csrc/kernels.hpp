@@ -33,6 +33,11 @@ bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
 hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                               int nframes, const GaussCoef& coef);
 
+// register-resident kernel for k = 11..17 (2 px per lane, LDS row exchange); width % 2 == 0, 8-byte aligned
+bool gauss_wide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+hipError_t launch_gauss_wide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                             const GaussCoef& coef);
+
 // impl: 0 = choose (sliding window when width % 4 == 0 and buffers aligned), 1 = force the LDS-tiled kernel
 hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                         int nframes, int impl);

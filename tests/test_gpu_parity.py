@@ -79,6 +79,31 @@ def test_gauss_sliding_window_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, si
     assert np.abs(slide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
 
 
+@pytest.mark.parametrize("k,sigma", [(11, 3.0), (13, 3.3), (15, 4.0), (17, 6.0)])
+@pytest.mark.parametrize("h,w", [(1, 2), (3, 6), (30, 100), (61, 112), (75, 114), (40, 252), (200, 640), (9, 3840)])
+def test_gauss_wide_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, sigma, h, w):
+    """gauss_wide.hip (k = 11..17, width % 2 == 0; 17/6 is the reference ProgramHandler's default) against
+    the LDS-tiled kernel (identical bits) and the CPU path (1 LSB)."""
+    img = rand_rgba(h, w, seed=h * 7 + w + k, alpha=None)
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(img, k, sigma)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    wide = ctx.gauss(img, k, sigma)
+    assert np.array_equal(wide, tiled)
+    if h * w <= 30000:
+        ref = oracle.gauss_rgba(img, k, sigma)
+        assert np.abs(wide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+
+
+def test_gauss_wide_kernel_batched_multi_band(ctx, pkg, oracle):
+    frames = oracle.synth_rgba(1000, 420, 3, first_frame=1, mode=1)
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(frames, 17, 6.0)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    assert np.array_equal(ctx.gauss(frames, 17, 6.0), tiled)
+
+
 def test_gauss_sliding_window_batched_multi_band(ctx, pkg, oracle):
     """Several frames, several bands per frame (h > 128), several strips (w > 248), edge strips."""
     frames = oracle.synth_rgba(1000, 300, 3, first_frame=1, mode=1)
