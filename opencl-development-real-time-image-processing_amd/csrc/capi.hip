@@ -50,6 +50,7 @@ struct mi355_ctx {
     int last_hip = 0;
     char name[256] = {};
     std::vector<CoefEntry> coefs;
+    std::vector<void*> pinned;  // mi355_host_alloc blocks still outstanding (freed at destroy)
 };
 
 namespace {
@@ -132,7 +133,14 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
     std::memcpy(host.data(), w2d, sizeof(float) * (size_t)k * k);
     separable_factor(k, w2d, host.data() + (size_t)k * k);
     // blocking copy from pageable memory: the table is live on the device when this returns
-    HIP_TRY(ctx, hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice));
+    const hipError_t ce = hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice);
+    if (ce != hipSuccess) {
+        // never leave a half-installed table behind: a later call with this (k, sigma) would find it
+        ctx->last_hip = (int)ce;
+        (void)hipFree(slot->d_buf);
+        ctx->coefs.erase(ctx->coefs.begin() + (slot - ctx->coefs.data()));
+        return MI355_ERR_HIP;
+    }
     slot->coef.k = k;
     slot->coef.d_w2d = slot->d_buf;
     slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
@@ -370,6 +378,8 @@ MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& e : ctx->coefs)
         (void)hipFree(e.d_buf);
+    for (void* p : ctx->pinned)
+        (void)hipHostFree(p);
     if (ctx->d_in)
         (void)hipFree(ctx->d_in);
     if (ctx->d_out)
@@ -529,6 +539,7 @@ MI355_API int mi355_host_alloc(mi355_ctx* ctx, size_t nbytes, void** h_ptr)
         *h_ptr = nullptr;
         return MI355_ERR_NOMEM;
     }
+    ctx->pinned.push_back(*h_ptr);
     return MI355_OK;
 }
 
@@ -536,9 +547,15 @@ MI355_API int mi355_host_free(mi355_ctx* ctx, void* h_ptr)
 {
     if (!ctx)
         return MI355_ERR_BAD_ARG;
-    if (h_ptr)
-        HIP_TRY(ctx, hipHostFree(h_ptr));
-    return MI355_OK;
+    if (!h_ptr)
+        return MI355_OK;
+    for (size_t i = 0; i < ctx->pinned.size(); i++)
+        if (ctx->pinned[i] == h_ptr) {
+            ctx->pinned.erase(ctx->pinned.begin() + i);
+            HIP_TRY(ctx, hipHostFree(h_ptr));
+            return MI355_OK;
+        }
+    return MI355_ERR_BAD_ARG;  // not a block of this context
 }
 
 MI355_API int mi355_filter_stream(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h,
