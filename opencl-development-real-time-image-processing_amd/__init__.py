@@ -13,6 +13,8 @@ from .imgfilter import (  # noqa: F401
     GAUSS_EXACT,
     GAUSS_FAST,
     IMPL_AUTO,
+    INPUT_BGR,
+    INPUT_RGBA,
     IMPL_TILE,
     Context,
     Mi355Error,

@@ -45,6 +45,11 @@ struct mi355_ctx {
     void* slot_in[kSlots] = {};
     void* slot_out[kSlots] = {};
     size_t slot_in_cap = 0, slot_out_cap = 0;
+    int input_format = MI355_INPUT_RGBA;
+    void* d_raw = nullptr;  // BGR staging of the host-buffer calls
+    size_t d_raw_cap = 0;
+    void* slot_raw[3] = {};
+    size_t slot_raw_cap = 0;
     int gauss_mode = MI355_GAUSS_FAST;
     int impl = MI355_IMPL_AUTO;
     int last_hip = 0;
@@ -267,10 +272,16 @@ int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w,
         return MI355_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t npx = (size_t)w * h * nframes;
+    const bool bgr = ctx->input_format == MI355_INPUT_BGR;
     const size_t in_bytes = npx * 4, out_bytes = npx * (size_t)bpp;
     rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
     if (rc != MI355_OK)
         return rc;
+    if (bgr) {
+        rc = ensure(ctx, &ctx->d_raw, &ctx->d_raw_cap, npx * 3);
+        if (rc != MI355_OK)
+            return rc;
+    }
     rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
     if (rc != MI355_OK)
         return rc;
@@ -284,9 +295,15 @@ int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w,
     hipStream_t s = ctx->stream;
     const uint64_t host0 = now_ns();
     HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    if (bgr) {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw, in, npx * 3, hipMemcpyHostToDevice, s));
+    } else {
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (bgr)  // the BGR2RGBA expansion counts as kernel time
+        HIP_TRY(ctx, launch_bgr_to_rgba(s, static_cast<const uint8_t*>(ctx->d_raw), static_cast<uint8_t*>(ctx->d_in), npx));
     rc = dispatch_dev(ctx, filter, ctx->d_in, ctx->d_out, w, h, nframes, k, sigma);
     if (rc != MI355_OK)
         return rc;
@@ -382,6 +399,11 @@ MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
         (void)hipHostFree(p);
     if (ctx->d_in)
         (void)hipFree(ctx->d_in);
+    if (ctx->d_raw)
+        (void)hipFree(ctx->d_raw);
+    for (void* p : ctx->slot_raw)
+        if (p)
+            (void)hipFree(p);
     if (ctx->d_out)
         (void)hipFree(ctx->d_out);
     if (ctx->d_acc)
@@ -459,6 +481,29 @@ MI355_API int mi355_ctx_set_impl(mi355_ctx* ctx, int impl)
     if (!ctx || (impl != MI355_IMPL_AUTO && impl != MI355_IMPL_TILE))
         return MI355_ERR_BAD_ARG;
     ctx->impl = impl;
+    return MI355_OK;
+}
+
+MI355_API int mi355_ctx_set_input_format(mi355_ctx* ctx, int format)
+{
+    if (!ctx || (format != MI355_INPUT_RGBA && format != MI355_INPUT_BGR))
+        return MI355_ERR_BAD_ARG;
+    ctx->input_format = format;
+    return MI355_OK;
+}
+
+MI355_API int mi355_bgr_to_rgba8_dev(mi355_ctx* ctx, const void* d_bgr, void* d_rgba, int w, int h, int nframes)
+{
+    if (!ctx)
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(d_bgr, d_rgba, w, h, nframes);
+    if (rc != MI355_OK)
+        return rc;
+    if (reinterpret_cast<uintptr_t>(d_rgba) & 3u)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_bgr_to_rgba(ctx->stream, static_cast<const uint8_t*>(d_bgr), static_cast<uint8_t*>(d_rgba),
+                                    (size_t)w * h * nframes));
     return MI355_OK;
 }
 
@@ -591,7 +636,22 @@ MI355_API int mi355_filter_stream(mi355_ctx* ctx, int filter, const uint8_t* rgb
             HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_d2h[i], hipEventDisableTiming));
         }
     }
+    const bool bgr = ctx->input_format == MI355_INPUT_BGR;
+    const size_t in_bpp = bgr ? 3 : 4;
     const size_t in_chunk = fpx * 4 * chunk_frames, out_chunk = fpx * (size_t)bpp * chunk_frames;
+    if (bgr && ctx->slot_raw_cap < fpx * 3 * chunk_frames) {
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        for (int i = 0; i < NS; i++) {
+            if (ctx->slot_raw[i])
+                (void)hipFree(ctx->slot_raw[i]);
+            ctx->slot_raw[i] = nullptr;
+        }
+        ctx->slot_raw_cap = 0;
+        for (int i = 0; i < NS; i++)
+            if (hipMalloc(&ctx->slot_raw[i], fpx * 3 * chunk_frames) != hipSuccess)
+                return MI355_ERR_NOMEM;
+        ctx->slot_raw_cap = fpx * 3 * chunk_frames;
+    }
     if (ctx->slot_in_cap < in_chunk || ctx->slot_out_cap < out_chunk) {
         HIP_TRY(ctx, hipDeviceSynchronize());
         for (int i = 0; i < NS; i++) {
@@ -626,13 +686,16 @@ MI355_API int mi355_filter_stream(mi355_ctx* ctx, int filter, const uint8_t* rgb
         // input slot is free once the kernel of chunk c-NS has read it
         if (c >= NS)
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_h2d, ctx->ev_k[slot], 0));
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->slot_in[slot], rgba + (size_t)f0 * fpx * 4, fpx * 4 * nf,
-                                    hipMemcpyHostToDevice, ctx->s_h2d));
+        HIP_TRY(ctx, hipMemcpyAsync(bgr ? ctx->slot_raw[slot] : ctx->slot_in[slot], rgba + (size_t)f0 * fpx * in_bpp,
+                                    fpx * in_bpp * nf, hipMemcpyHostToDevice, ctx->s_h2d));
         HIP_TRY(ctx, hipEventRecord(ctx->ev_h2d[slot], ctx->s_h2d));
         // kernel: needs its input, and its output slot drained by the D2H of chunk c-NS
         HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[slot], 0));
         if (c >= NS)
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_d2h[slot], 0));
+        if (bgr)
+            HIP_TRY(ctx, launch_bgr_to_rgba(ctx->stream, static_cast<const uint8_t*>(ctx->slot_raw[slot]),
+                                            static_cast<uint8_t*>(ctx->slot_in[slot]), fpx * nf));
         rc = dispatch_dev(ctx, filter, ctx->slot_in[slot], ctx->slot_out[slot], w, h, nf, k, sigma);
         if (rc != MI355_OK) {
             (void)hipDeviceSynchronize();

@@ -53,6 +53,9 @@ hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d
 hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nframes,
                         int first_frame, uint32_t seed, int mode);
 
+// packed BGR (3 B/px) -> RGBA (A = 255), cv::cvtColor(BGR2RGBA)
+hipError_t launch_bgr_to_rgba(hipStream_t stream, const uint8_t* d_bgr, uint8_t* d_rgba, size_t npx);
+
 // *d_acc += order-independent checksum of nbytes at d_buf (see include/mi355_imgfilter.h)
 hipError_t launch_checksum(hipStream_t stream, const uint8_t* d_buf, size_t nbytes,
                            uint64_t index_base, unsigned long long* d_acc);

@@ -21,6 +21,7 @@ _HEADER = os.path.join(_ROOT, "include", "mi355_imgfilter.h")
 
 FILTER_GRAY, FILTER_GRAY1, FILTER_GAUSS, FILTER_SOBEL, FILTER_PIPELINE = 0, 1, 2, 3, 4
 GAUSS_FAST, GAUSS_EXACT = 0, 1
+INPUT_RGBA, INPUT_BGR = 0, 1
 IMPL_AUTO, IMPL_TILE = 0, 1
 OUT_BPP = {FILTER_GRAY: 4, FILTER_GRAY1: 1, FILTER_GAUSS: 4, FILTER_SOBEL: 1, FILTER_PIPELINE: 1}
 
@@ -73,6 +74,8 @@ def load_library():
         "mi355_sync": [_vp],
         "mi355_last_hip_error": [_vp],
         "mi355_ctx_set_gauss_mode": [_vp, _ci],
+        "mi355_ctx_set_input_format": [_vp, _ci],
+        "mi355_bgr_to_rgba8_dev": [_vp, _vp, _vp, _ci, _ci, _ci],
         "mi355_ctx_set_impl": [_vp, _ci],
         "mi355_gauss_weights": [_ci, ctypes.c_float, _f32p],
         "mi355_ctx_set_gauss_weights": [_vp, _ci, ctypes.c_float, _f32p],
@@ -181,6 +184,11 @@ class Context:
     def set_gauss_mode(self, mode):
         _check("mi355_ctx_set_gauss_mode", self._lib.mi355_ctx_set_gauss_mode(self._h, int(mode)), self._h)
 
+    def set_input_format(self, fmt):
+        """INPUT_RGBA (default) or INPUT_BGR: host-buffer calls then take (h, w, 3) / (n, h, w, 3) BGR frames."""
+        _check("mi355_ctx_set_input_format", self._lib.mi355_ctx_set_input_format(self._h, int(fmt)), self._h)
+        self._in_ch = 3 if fmt == INPUT_BGR else 4
+
     def set_impl(self, impl):
         _check("mi355_ctx_set_impl", self._lib.mi355_ctx_set_impl(self._h, int(impl)), self._h)
 
@@ -201,8 +209,8 @@ class Context:
         else:
             raise Mi355Error("filter", -1, "expected (h, w, 4) or (n, h, w, 4) uint8")
         n, h, w, c = frames.shape
-        if c != 4:
-            raise Mi355Error("filter", -1, "expected RGBA (4 channels)")
+        if c != getattr(self, "_in_ch", 4):
+            raise Mi355Error("filter", -1, "expected %d channels per pixel" % getattr(self, "_in_ch", 4))
         bpp = OUT_BPP[filt]
         out = np.empty((n, h, w, 4) if bpp == 4 else (n, h, w), np.uint8)
         prof = (ctypes.c_uint64 * 6)()
@@ -250,7 +258,8 @@ class Context:
     def stream(self, filt, frames, out=None, k=0, sigma=0.0, chunk_frames=0):
         """mi355_filter_stream: overlapped H2D / kernel / D2H over a host batch.  Returns (out, elapsed_ms)."""
         assert frames.flags["C_CONTIGUOUS"] and frames.dtype == np.uint8 and frames.ndim == 4
-        n, h, w, _ = frames.shape
+        n, h, w, c = frames.shape
+        assert c == getattr(self, "_in_ch", 4)
         bpp = OUT_BPP[filt]
         if out is None:
             out = np.empty((n, h, w, 4) if bpp == 4 else (n, h, w), np.uint8)

@@ -266,6 +266,34 @@ def test_streamed_host_path_equals_batched(ctx, pkg, oracle):
     ctx.pinned_free(pin_out)
 
 
+def test_bgr_input_format(ctx, pkg, oracle, fixture_rgb):
+    """3-byte BGR frames (what cv::imread hands the reference): the device performs cvtColor(BGR2RGBA)."""
+    rng = np.random.default_rng(3)
+    for (h, w) in ((1, 1), (5, 7), (33, 250), (64, 256)):
+        bgr = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        rgba = np.concatenate([bgr[..., ::-1], np.full((2, h, w, 1), 255, np.uint8)], axis=-1)
+        ctx.set_input_format(pkg.INPUT_BGR)
+        try:
+            g1, gs, ga, pp = ctx.gray1(bgr), ctx.sobel(bgr), ctx.gauss(bgr, 5, 1.5), ctx.pipeline(bgr, 5, 1.5)
+            st, _ = ctx.stream(pkg.FILTER_GAUSS, bgr, k=5, sigma=1.5, chunk_frames=1)
+        finally:
+            ctx.set_input_format(pkg.INPUT_RGBA)
+        for f in range(2):
+            assert np.array_equal(g1[f], oracle.gray_bgr(bgr[f]))        # the reference CPU path's own layout
+        assert np.array_equal(gs, ctx.sobel(rgba))
+        assert np.array_equal(ga, ctx.gauss(rgba, 5, 1.5))
+        assert np.array_equal(pp, ctx.pipeline(rgba, 5, 1.5))
+        assert np.array_equal(st, ga)
+    # BASELINE.json config 1 through the GPU: grayscale of the Tulips fixture in its native BGR layout
+    bgr = np.ascontiguousarray(fixture_rgb[..., ::-1])
+    ctx.set_input_format(pkg.INPUT_BGR)
+    try:
+        got = ctx.gray1(bgr)
+    finally:
+        ctx.set_input_format(pkg.INPUT_RGBA)
+    assert np.array_equal(got, oracle.gray_bgr(bgr))
+
+
 def test_per_frame_entry_points_and_profiling_contract(ctx, oracle):
     """mi355_*_rgba8: six timestamps, write/kernel/read, non-decreasing (Controller.cpp:66-74)."""
     img = rand_rgba(64, 96, seed=4)

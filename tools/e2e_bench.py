@@ -65,6 +65,20 @@ def main():
         _, ms = ctx.stream(filt, pin_in, out=o1, k=k, sigma=sigma, chunk_frames=2)
         res["streamed_pinned_%s" % name] = {"Mpix_s": px / (ms * 1e-3) / 1e6, "ms_per_frame": ms / n}
         ctx.pinned_free(o1)
+    # 3-byte BGR frames (cv::imread layout): 25 % fewer bytes over PCIe, BGR2RGBA done on the device
+    ctx.set_input_format(pkg.INPUT_BGR)
+    pin_bgr = ctx.pinned_empty((n, h, w, 3))
+    pin_bgr[...] = frames[..., 2::-1]
+    for filt, name, shape in ((pkg.FILTER_GAUSS, "gauss", (n, h, w, 4)), (pkg.FILTER_PIPELINE, "pipeline", (n, h, w))):
+        o1 = ctx.pinned_empty(shape)
+        ctx.stream(filt, pin_bgr, out=o1, k=k, sigma=sigma, chunk_frames=2)
+        _, ms = ctx.stream(filt, pin_bgr, out=o1, k=k, sigma=sigma, chunk_frames=2)
+        res["streamed_pinned_bgr_%s" % name] = {"Mpix_s": px / (ms * 1e-3) / 1e6, "ms_per_frame": ms / n}
+        if name == "gauss":
+            assert np.array_equal(o1, pin_out)
+        ctx.pinned_free(o1)
+    ctx.set_input_format(pkg.INPUT_RGBA)
+    ctx.pinned_free(pin_bgr)
     ctx.pinned_free(pin_in)
     ctx.pinned_free(pin_out)
     print(json.dumps(res, indent=1))
