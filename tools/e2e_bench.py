@@ -75,7 +75,7 @@ def main():
         _, ms = ctx.stream(filt, pin_bgr, out=o1, k=k, sigma=sigma, chunk_frames=2)
         res["streamed_pinned_bgr_%s" % name] = {"Mpix_s": px / (ms * 1e-3) / 1e6, "ms_per_frame": ms / n}
         if name == "gauss":
-            assert np.array_equal(o1, pin_out)
+            assert np.array_equal(o1[..., :3], pin_out[..., :3])  # alpha differs: the test frames' A is random
         ctx.pinned_free(o1)
     ctx.set_input_format(pkg.INPUT_RGBA)
     ctx.pinned_free(pin_bgr)
