@@ -1,9 +1,12 @@
 #!/bin/bash
-# tools/sweep.sh — quick A/B of tuning knobs through bench.py (each line: knob value -> GB/s)
+# tools/sweep.sh — A/B of one tuning knob through bench.py on the GPU box.
+#   tools/sweep.sh <filter> <ENV_VAR> <v1> <v2> ... [-- extra bench args]
+# e.g. tools/sweep.sh gauss MI355_TUNE_BAND_ROWS 96 128 216 -- --frames 64
+# Knobs (read once per process, tuning only): MI355_TUNE_BAND_ROWS, MI355_TUNE_TAIL_ROWS,
+# MI355_TUNE_TAIL_FRAC (sliding-window band plan, slide_common.hpp), MI355_TUNE_GRAY_BLOCKS (gray.hip).
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-run() { python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ceiling "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f GB/s  %7.3f ms' % (d['roofline']['achieved'], d['roofline']['avg_launch_ms']))"; }
-for b in 32 64 128 256 540 2160; do echo -n "band_rows=$b: "; MI355_TUNE_BAND_ROWS=$b run; done
-for f in 16 32 64 128; do echo -n "frames=$f: "; run --frames $f; done
-echo -n "1080p frames=256: "; run --width 1920 --height 1080 --frames 256
-for k in 3 7 9; do echo -n "k=$k: "; run --k $k; done
-echo -n "synth mode 1: "; run --synth-mode 1
+F=$1; VAR=$2; shift 2
+VALS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do VALS+=("$1"); shift; done; [ "${1:-}" = "--" ] && shift
+run() { python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling --filter $F "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f GB/s  frac %.3f  %7.3f ms  %.0f Mpx/s' % (d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['value']))"; }
+echo -n "$F default: "; run "$@"
+for v in "${VALS[@]}"; do echo -n "$F $VAR=$v: "; env $VAR=$v python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling --filter $F "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f GB/s  frac %.3f  %7.3f ms  %.0f Mpx/s' % (d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['avg_launch_ms'], d['value']))"; done
