@@ -50,6 +50,9 @@ def parse():
     p.add_argument("--sigma", type=float, default=1.5)
     p.add_argument("--mode", default="fast", choices=["fast", "exact"])
     p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise")
+    p.add_argument("--random-alpha", action="store_true", help="overwrite the frames' alpha (255 by definition "
+                   "of the synthetic frames, as after cvtColor BGR2RGBA) with noise: measures the Gaussian's "
+                   "general 4-channel path instead of its opaque fast path")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
@@ -134,6 +137,8 @@ def main():
     d_out = torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev)[:F]
     first_frame = rank * F
     ctx.synth_dev(d_in.data_ptr(), w, h, F, first_frame=first_frame, seed=0x5EED, mode=args.synth_mode)
+    if args.random_alpha:
+        d_in[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
 
     # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes
     if args.filter in ("gauss", "pipeline"):
@@ -225,7 +230,8 @@ def main():
             "data": "synthetic (device-generated counter-hash frames, resident in HBM before timing)",
             "config": {"workload": "%s k=%d sigma=%g, %dx%d RGBA, %d frames/GPU/step, mode=%s" %
                                    (args.filter, args.k, args.sigma, w, h, F, args.mode),
-                       "frames_per_gpu": F, "width": w, "height": h, "parallelism": "frames sharded x%d" % world},
+                       "frames_per_gpu": F, "width": w, "height": h, "parallelism": "frames sharded x%d" % world,
+                       "alpha": "random" if args.random_alpha else "255 (opaque frames, as after cvtColor BGR2RGBA)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,

@@ -20,7 +20,9 @@
 //    pixel into the halo lane at load time, so the arithmetic itself has no border cases.
 // Algorithmic bytes: 8 B/px.  Extra traffic: halo lanes (2/62 of the loads, L2/MALL hits) and 2R
 // warm-up rows per band.  VALU: 2*K FMA per channel + 1 cvt in + 1 cvt/pack out.  Bound: HBM.
+#include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -94,6 +96,35 @@ __device__ __forceinline__ void cvt_pack4x4(const float (&h)[4][4] /* [channel][
     o = u32x4{o0, o1, o2, o3};
 }
 
+// Same for the opaque fast path: three channels converted, the alpha byte is a wave-uniform constant
+// (already shifted to bits 31:24).  The v_or that merges it reads its register three instructions after the
+// last partial write of it.
+__device__ __forceinline__ void cvt_pack3x4(const float (&h)[4][4] /* [channel][pixel] */, uint32_t alpha_hi,
+                                            u32x4& o)
+{
+    uint32_t o0, o1, o2, o3;
+    asm("v_cvt_u32_f32_e32 %0, %4\n\t"
+        "v_cvt_u32_f32_e32 %1, %5\n\t"
+        "v_cvt_u32_f32_e32 %2, %6\n\t"
+        "v_cvt_u32_f32_e32 %3, %7\n\t"
+        "v_cvt_u32_f32_sdwa %0, %8 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %1, %9 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %2, %10 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %3, %11 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %0, %12 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %1, %13 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %2, %14 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_cvt_u32_f32_sdwa %3, %15 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD\n\t"
+        "v_or_b32_e32 %0, %16, %0\n\t"
+        "v_or_b32_e32 %1, %16, %1\n\t"
+        "v_or_b32_e32 %2, %16, %2\n\t"
+        "v_or_b32_e32 %3, %16, %3"
+        : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)
+        : "v"(h[0][0]), "v"(h[0][1]), "v"(h[0][2]), "v"(h[0][3]), "v"(h[1][0]), "v"(h[1][1]), "v"(h[1][2]),
+          "v"(h[1][3]), "v"(h[2][0]), "v"(h[2][1]), "v"(h[2][2]), "v"(h[2][3]), "s"(alpha_hi));
+    o = u32x4{o0, o1, o2, o3};
+}
+
 template <bool CLAMP>
 __device__ __forceinline__ uint32_t to_u8(float a)
 {
@@ -152,48 +183,31 @@ __device__ __forceinline__ void hpass5_dpp(float v0, float v1, float v2, float v
         : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(w4));
 }
 
-template <int R, bool CLAMP>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
-    int lanes_out, BandPlan plan, Weights<2 * R + 1> wts)
+// What a wave needs to know about its work item, computed once in the kernel
+struct SlideLane {
+    const uint8_t* fin;
+    uint8_t* fout;
+    size_t row_bytes;
+    uint32_t in_off, out_off;
+    int y0, nout, nin, h;
+    bool left_of_image, right_of_image, edge_strip, stores;
+};
+
+// One pass over the band with NCH channels computed per pixel.  NCH = 4: the general path.  NCH = 3: the
+// opaque fast path — alpha is not computed, every output gets the constant byte alpha_hi; each loaded row is
+// tested (one ballot over all 64 lanes, halo included) and the pass returns false at the first alpha != 255,
+// before that row has contributed anything: the rows stored so far are correct, and the caller redoes the band
+// with NCH = 4.
+template <int R, bool CLAMP, int NCH>
+__device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi)
 {
     constexpr int K = 2 * R + 1;
-    const int lane = threadIdx.x & 63;
-    SlideItem it;
-    if (!slide_item(plan, nstrips, h, &it))
-        return;
-    const int strip = it.strip, y0 = it.y0, nout = it.nout;
-    const size_t frame = it.frame;
-
-    const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
-    const int q_load = clampi(q_lane, 0, quads - 1);   // replicated at the image border
-    const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
-    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
-    const int q_end = min((strip + 1) * lanes_out, quads);
-    const bool stores = (lane >= 1) && (q_lane < q_end);
-
-    const int nin = nout + 2 * R;
-
-    const size_t row_bytes = (size_t)quads * 16;
-    const uint8_t* fin = in + frame * row_bytes * h;    // uniform base; lanes add a 32-bit offset
-    uint8_t* fout = out + frame * row_bytes * h;
-    const uint32_t in_off = (uint32_t)q_load * 16u;
-    const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 16u;
-
-    // weights live in VGPRs: the DPP forms (v_mul_f32_dpp / v_fmac_f32_dpp) take no SGPR operand
-    float wv[K];
-#pragma unroll
-    for (int j = 0; j < K; j++) {
-        wv[j] = wts.w[j];
-        asm volatile("" : "+v"(wv[j]));
-    }
-
     auto load_row = [&](int i) -> u32x4 {
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
-        const int y = clampi(y0 - R + min(i, nin - 1), 0, h - 1);
-        const uint8_t* rowp = fin + (size_t)y * row_bytes;
+        const int y = clampi(L.y0 - R + min(i, L.nin - 1), 0, L.h - 1);
+        const uint8_t* rowp = L.fin + (size_t)y * L.row_bytes;
         // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
-        return *reinterpret_cast<const u32x4*>(rowp + in_off);
+        return *reinterpret_cast<const u32x4*>(rowp + L.in_off);
     };
 
     // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
@@ -204,39 +218,44 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
-    float acc[K][16] = {};
+    float acc[K][4 * NCH] = {};
 
     // One trip = K input rows; input row i is tap j of output row m = i - j (m in slot m % K).  The
     // first 2R rows of a band and the rows of a last partial trip run the same code with their
     // store masked off: no control flow inside the trip except the store predicate.
-    for (int base = 0; base < nin; base += K) {
+    for (int base = 0; base < L.nin; base += K) {
 #pragma unroll
         for (int u = 0; u < K; u++) {
             const int i = base + u;
             u32x4 p = q[u];
             q[(u + PF) % K] = load_row(i + PF);
-            if (edge_strip) {
+            if (L.edge_strip) {
                 // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
-                if (left_of_image)
+                if (L.left_of_image)
                     p = u32x4{p.x, p.x, p.x, p.x};
-                if (right_of_image)
+                if (L.right_of_image)
                     p = u32x4{p.w, p.w, p.w, p.w};
             }
-            // vertical pass, pixel by pixel: convert one pixel's 4 channels, fold them into all K
-            // accumulators (input row i is tap j of output row i - j), then move on — 4 live temporaries
+            if constexpr (NCH == 3) {
+                const uint32_t a4 = p.x & p.y & p.z & p.w;
+                if (__builtin_amdgcn_ballot_w64((a4 >> 24) != 0xFFu) != 0)  // wave-uniform
+                    return false;
+            }
+            // vertical pass, pixel by pixel: convert one pixel's channels, fold them into all K
+            // accumulators (input row i is tap j of output row i - j), then move on — few live temporaries
 #pragma unroll
             for (int px = 0; px < 4; px++) {
-                float f[4];
+                float f[NCH];
 #pragma unroll
-                for (int c = 0; c < 4; c++)
+                for (int c = 0; c < NCH; c++)
                     f[c] = ubyte_f32(p[px], c);
 #pragma unroll
                 for (int j = 0; j < K; j++) {
                     const int s = (u - j + K) % K;
 #pragma unroll
-                    for (int c = 0; c < 4; c++)
-                        acc[s][px * 4 + c] =
-                            (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], acc[s][px * 4 + c]);
+                    for (int c = 0; c < NCH; c++)
+                        acc[s][px * NCH + c] =
+                            (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], acc[s][px * NCH + c]);
                 }
             }
             const int m = i - 2 * R;  // output row that just received its last tap
@@ -245,46 +264,98 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
             if constexpr (R == 2) {
                 float hres[4][4];  // [channel][pixel]
 #pragma unroll
-                for (int c = 0; c < 4; c++)
-                    hpass5_dpp(v[0 + c], v[4 + c], v[8 + c], v[12 + c], wv[0], wv[1], wv[2], wv[3], wv[4],
-                               hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
+                for (int c = 0; c < NCH; c++)
+                    hpass5_dpp(v[0 * NCH + c], v[1 * NCH + c], v[2 * NCH + c], v[3 * NCH + c], wv[0], wv[1], wv[2],
+                               wv[3], wv[4], hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
                 if constexpr (CLAMP) {
 #pragma unroll
                     for (int px = 0; px < 4; px++)
-                        o[px] = pack_px<true>(hres[0][px], hres[1][px], hres[2][px], hres[3][px]);
-                } else {
+                        o[px] = (NCH == 4) ? pack_px<true>(hres[0][px], hres[1][px], hres[2][px], hres[3][px])
+                                           : (pack_px<true>(hres[0][px], hres[1][px], hres[2][px], 0.0f) | alpha_hi);
+                } else if constexpr (NCH == 4) {
                     cvt_pack4x4(hres, o);
+                } else {
+                    cvt_pack3x4(hres, alpha_hi, o);
                 }
             } else {
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
-                    float r4[4];
+                    float r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
+                    for (int c = 0; c < NCH; c++) {
                         float sum = 0.0f;
 #pragma unroll
                         for (int t = 0; t < K; t++) {
                             const int s = px - R + t;
                             float src;
                             if (s < 0)
-                                src = dpp_from_left(v[(4 + s) * 4 + c]);
+                                src = dpp_from_left(v[(4 + s) * NCH + c]);
                             else if (s > 3)
-                                src = dpp_from_right(v[(s - 4) * 4 + c]);
+                                src = dpp_from_right(v[(s - 4) * NCH + c]);
                             else
-                                src = v[s * 4 + c];
+                                src = v[s * NCH + c];
                             sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
                         }
                         r4[c] = sum;
                     }
                     o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
+                    if constexpr (NCH == 3)
+                        o[px] |= alpha_hi;
                 }
             }
-            if (stores && m >= 0 && m < nout) {
-                uint8_t* rowp = fout + (size_t)(y0 + m) * row_bytes;
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + out_off));
+            if (L.stores && m >= 0 && m < L.nout) {
+                uint8_t* rowp = L.fout + (size_t)(L.y0 + m) * L.row_bytes;
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + L.out_off));
             }
         }
     }
+    return true;
+}
+
+template <int R, bool CLAMP>
+__global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
+    int lanes_out, BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi)
+{
+    constexpr int K = 2 * R + 1;
+    const int lane = threadIdx.x & 63;
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
+        return;
+    const int strip = it.strip;
+
+    const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
+    const int q_load = clampi(q_lane, 0, quads - 1);   // replicated at the image border
+    const int q_end = min((strip + 1) * lanes_out, quads);
+    SlideLane L;
+    L.left_of_image = q_lane < 0;
+    L.right_of_image = q_lane >= quads;
+    L.edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    L.stores = (lane >= 1) && (q_lane < q_end);
+    L.y0 = it.y0;
+    L.nout = it.nout;
+    L.nin = it.nout + 2 * R;
+    L.h = h;
+    L.row_bytes = (size_t)quads * 16;
+    L.fin = in + it.frame * L.row_bytes * h;  // uniform base; lanes add a 32-bit offset
+    L.fout = out + it.frame * L.row_bytes * h;
+    L.in_off = (uint32_t)q_load * 16u;
+    L.out_off = (uint32_t)(L.stores ? q_lane : 0) * 16u;
+
+    // weights live in VGPRs: the DPP forms (v_mul_f32_dpp / v_fmac_f32_dpp) take no SGPR operand
+    float wv[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        wv[j] = wts.w[j];
+        asm volatile("" : "+v"(wv[j]));
+    }
+
+    // Opaque fast path first (frames from cv::cvtColor(BGR2RGBA) have A = 255 everywhere,
+    // RT/src/ProgramHandler.cpp:127): with every alpha tap 255 the blurred alpha is one constant byte, which
+    // the host computes with the same float chain (std::fmaf) — 25 % of the arithmetic gone, same bits.
+    // A band that meets any other alpha value is redone in full.
+    if (!gauss_slide_band<R, CLAMP, 3>(L, wv, alpha_hi))
+        gauss_slide_band<R, CLAMP, 4>(L, wv, alpha_hi);
 }
 
 template <int R>
@@ -305,12 +376,24 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     for (int j = 0; j < K; j++)
         wsum += (double)coef.h_w1d[j];
     const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);  // externally installed tables may overflow
+    // constant alpha byte of the opaque fast path: the canonical chains on an all-255 channel, in float
+    uint32_t alpha_hi;
+    {
+        float vc = wts.w[0] * 255.0f;
+        for (int t = 1; t < K; t++)
+            vc = std::fmaf(wts.w[t], 255.0f, vc);  // finished vertical sum
+        float hc = wts.w[0] * vc;
+        for (int t = 1; t < K; t++)
+            hc = std::fmaf(wts.w[t], vc, hc);
+        hc = hc < 0.0f ? 0.0f : (hc > 255.0f ? 255.0f : hc);  // uchar(std::clamp(.)) of the CPU path
+        alpha_hi = (uint32_t)hc << 24;
+    }
     if (clamp)
         hipLaunchKernelGGL((gauss_slide_kernel<R, true>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts);
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts, alpha_hi);
     else
         hipLaunchKernelGGL((gauss_slide_kernel<R, false>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts);
+                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts, alpha_hi);
     return hipGetLastError();
 }
 

@@ -104,6 +104,44 @@ def test_gauss_wide_kernel_batched_multi_band(ctx, pkg, oracle):
     assert np.array_equal(ctx.gauss(frames, 17, 6.0), tiled)
 
 
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0), (9, 2.5)])
+def test_gauss_opaque_fast_path_and_its_fallback(ctx, pkg, oracle, k, sigma):
+    """The sliding-window kernel skips the alpha arithmetic while every alpha byte a wave sees is 255 and redoes
+    the band in full otherwise.  Opaque frames, frames with ONE non-opaque pixel (at band / strip / halo
+    boundaries and in the image corners), and a non-opaque frame must all equal the tiled kernel bit for bit
+    and the CPU path within 1 LSB (alpha included: a blurred all-255 channel is 254 or 255)."""
+    h, w = 300, 512   # several bands (tall and tail), 3 strips
+    base = oracle.synth_rgba(w, h, 1, first_frame=k, mode=1)[0]   # A = 255 everywhere
+    cases = [None, (0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (1, 239), (150, 240), (151, 243), (127, 100),
+             (128, 100), (269, 300), (270, 511), (299, 256)]
+    ref_opaque = None
+    for pos in cases:
+        img = base.copy()
+        if pos is not None:
+            img[pos[0], pos[1], 3] = 7
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        ctx.set_impl(pkg.IMPL_TILE)
+        tiled = ctx.gauss(img, k, sigma)
+        ctx.set_impl(pkg.IMPL_AUTO)
+        slide = ctx.gauss(img, k, sigma)
+        assert np.array_equal(slide, tiled), pos
+        if pos is None:
+            ref_opaque = slide
+            assert set(np.unique(slide[..., 3]).tolist()) <= {254, 255}
+            ref = oracle.gauss_rgba(img, k, sigma)
+            assert np.abs(slide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+        else:
+            # far from the transparent pixel nothing changes
+            far = np.ones((h, w), bool)
+            far[max(0, pos[0] - k):pos[0] + k + 1, max(0, pos[1] - k):pos[1] + k + 1] = False
+            assert np.array_equal(slide[far], ref_opaque[far]), pos
+    noisy = rand_rgba(h, w, seed=k, alpha=None)
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(noisy, k, sigma)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    assert np.array_equal(ctx.gauss(noisy, k, sigma), tiled)
+
+
 def test_gauss_sliding_window_batched_multi_band(ctx, pkg, oracle):
     """Several frames, several bands per frame (h > 128), several strips (w > 248), edge strips."""
     frames = oracle.synth_rgba(1000, 300, 3, first_frame=1, mode=1)
