@@ -96,6 +96,20 @@ def test_gauss_wide_kernel_equals_tiled_kernel(ctx, pkg, oracle, k, sigma, h, w)
         assert np.abs(wide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
 
 
+def test_gauss_wide_kernel_opaque_fast_path_and_fallback(ctx, pkg, oracle):
+    h, w = 200, 300
+    base = oracle.synth_rgba(w, h, 1, first_frame=3, mode=1)[0]   # A = 255
+    for pos in (None, (0, 0), (199, 299), (100, 111), (100, 112), (137, 5), (64, 223)):
+        img = base.copy()
+        if pos is not None:
+            img[pos[0], pos[1], 3] = 200
+        for k, sigma in ((11, 3.0), (17, 6.0)):
+            ctx.set_impl(pkg.IMPL_TILE)
+            tiled = ctx.gauss(img, k, sigma)
+            ctx.set_impl(pkg.IMPL_AUTO)
+            assert np.array_equal(ctx.gauss(img, k, sigma), tiled), (pos, k)
+
+
 def test_gauss_wide_kernel_batched_multi_band(ctx, pkg, oracle):
     frames = oracle.synth_rgba(1000, 420, 3, first_frame=1, mode=1)
     ctx.set_impl(pkg.IMPL_TILE)
