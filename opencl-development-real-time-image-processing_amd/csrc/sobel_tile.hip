@@ -85,7 +85,7 @@ __global__ __launch_bounds__(kThreads) void sobel_tile_kernel(const uint32_t* __
         // positions beyond (w, h) are never consumed by a stored pixel: fold them onto w / h first
         const int py = min(y0 - 1 + ly, h), px = min(x0 - 1 + lx, w);
         const int gy = reflect101(py, h), gx = reflect101(px, w);
-        L[i] = (int)luma_px(fin[(size_t)gy * w + gx]);
+        L[i] = (int)luma_px_fast(fin[(size_t)gy * w + gx]);
     }
     __syncthreads();
     sobel_from_tile(L, fout, w, h, x0, y0, tid, vec_store != 0);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void pipeline_tile_kernel(const uint32_t*
         const int ly = i / GW, lx = i - ly * GW;
         const int gy = clampi(y0 - 1 - R + ly, 0, h - 1);
         const int gx = clampi(x0 - 1 - R + lx, 0, w - 1);
-        G[i] = (float)luma_px(fin[(size_t)gy * w + gx]);
+        G[i] = luma_px_fast(fin[(size_t)gy * w + gx]);
     }
     __syncthreads();
 
