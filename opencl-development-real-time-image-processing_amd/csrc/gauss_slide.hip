@@ -191,6 +191,10 @@ struct SlideLane {
     uint32_t in_off, out_off;
     int y0, nout, nin, h;
     bool left_of_image, right_of_image, edge_strip, stores;
+    // RAGGED variant (width % 4 != 0 or buffers not 16-byte aligned): in the two edge strips every lane
+    // addresses its 4 pixels one by one, clamped to the row (which is also what replicates the edge pixel)
+    uint32_t px_off[4];   // byte offsets of the 4 (clamped) pixels inside a row
+    int x_lane, w;        // first pixel of the lane (may be < 0 or >= w), image width
 };
 
 // One pass over the band with NCH channels computed per pixel.  NCH = 4: the general path.  NCH = 3: the
@@ -198,7 +202,7 @@ struct SlideLane {
 // tested (one ballot over all 64 lanes, halo included) and the pass returns false at the first alpha != 255,
 // before that row has contributed anything: the rows stored so far are correct, and the caller redoes the band
 // with NCH = 4.
-template <int R, bool CLAMP, int NCH>
+template <int R, bool CLAMP, int NCH, bool RAGGED>
 __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi)
 {
     constexpr int K = 2 * R + 1;
@@ -206,8 +210,22 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
         const int y = clampi(L.y0 - R + min(i, L.nin - 1), 0, L.h - 1);
         const uint8_t* rowp = L.fin + (size_t)y * L.row_bytes;
-        // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
-        return *reinterpret_cast<const u32x4*>(rowp + L.in_off);
+        if constexpr (RAGGED) {
+            if (L.edge_strip) {  // wave-uniform
+                u32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    r[j] = *reinterpret_cast<const uint32_t*>(rowp + L.px_off[j]);
+                return r;
+            }
+            // interior strip: all 4 pixels are inside the row, but the row is only 4-byte aligned
+            u32x4 r;
+            __builtin_memcpy(&r, rowp + L.in_off, 16);
+            return r;
+        } else {
+            // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
+            return *reinterpret_cast<const u32x4*>(rowp + L.in_off);
+        }
     };
 
     // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
@@ -229,12 +247,14 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
             const int i = base + u;
             u32x4 p = q[u];
             q[(u + PF) % K] = load_row(i + PF);
-            if (L.edge_strip) {
-                // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
-                if (L.left_of_image)
-                    p = u32x4{p.x, p.x, p.x, p.x};
-                if (L.right_of_image)
-                    p = u32x4{p.w, p.w, p.w, p.w};
+            if constexpr (!RAGGED) {
+                if (L.edge_strip) {
+                    // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
+                    if (L.left_of_image)
+                        p = u32x4{p.x, p.x, p.x, p.x};
+                    if (L.right_of_image)
+                        p = u32x4{p.w, p.w, p.w, p.w};
+                }
             }
             if constexpr (NCH == 3) {
                 const uint32_t a4 = p.x & p.y & p.z & p.w;
@@ -305,18 +325,30 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
             }
             if (L.stores && m >= 0 && m < L.nout) {
                 uint8_t* rowp = L.fout + (size_t)(L.y0 + m) * L.row_bytes;
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + L.out_off));
+                if constexpr (RAGGED) {
+                    if (L.edge_strip) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (L.x_lane + j < L.w)  // the last quad of a row may be partial
+                                *reinterpret_cast<uint32_t*>(rowp + L.out_off + 4 * j) = o[j];
+                    } else {
+                        __builtin_memcpy(rowp + L.out_off, &o, 16);
+                    }
+                } else {
+                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + L.out_off));
+                }
             }
         }
     }
     return true;
 }
 
-template <int R, bool CLAMP>
+template <int R, bool CLAMP, bool RAGGED>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
-    int lanes_out, BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi)
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
+    BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi)
 {
+    const int quads = (w + 3) >> 2;  // RAGGED: the last quad of a row may hold fewer than 4 pixels
     constexpr int K = 2 * R + 1;
     const int lane = threadIdx.x & 63;
     SlideItem it;
@@ -330,17 +362,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     SlideLane L;
     L.left_of_image = q_lane < 0;
     L.right_of_image = q_lane >= quads;
-    L.edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    // edge strip = a wave that touches pixels outside [0, w): wave-uniform
+    L.edge_strip = (strip == 0) || (4 * (strip * lanes_out + 63) > w);
     L.stores = (lane >= 1) && (q_lane < q_end);
     L.y0 = it.y0;
     L.nout = it.nout;
     L.nin = it.nout + 2 * R;
     L.h = h;
-    L.row_bytes = (size_t)quads * 16;
+    L.w = w;
+    L.x_lane = 4 * q_lane;
+    L.row_bytes = (size_t)w * 4;
     L.fin = in + it.frame * L.row_bytes * h;  // uniform base; lanes add a 32-bit offset
     L.fout = out + it.frame * L.row_bytes * h;
     L.in_off = (uint32_t)q_load * 16u;
     L.out_off = (uint32_t)(L.stores ? q_lane : 0) * 16u;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        L.px_off[j] = (uint32_t)clampi(4 * q_lane + j, 0, w - 1) * 4u;
 
     // weights live in VGPRs: the DPP forms (v_mul_f32_dpp / v_fmac_f32_dpp) take no SGPR operand
     float wv[K];
@@ -354,8 +392,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     // RT/src/ProgramHandler.cpp:127): with every alpha tap 255 the blurred alpha is one constant byte, which
     // the host computes with the same float chain (std::fmaf) — 25 % of the arithmetic gone, same bits.
     // A band that meets any other alpha value is redone in full.
-    if (!gauss_slide_band<R, CLAMP, 3>(L, wv, alpha_hi))
-        gauss_slide_band<R, CLAMP, 4>(L, wv, alpha_hi);
+    if (!gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi))
+        gauss_slide_band<R, CLAMP, 4, RAGGED>(L, wv, alpha_hi);
 }
 
 template <int R>
@@ -364,7 +402,9 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
 {
     constexpr int K = 2 * R + 1;
     const StripPlan sp = make_strip_plan(w);
-    const int quads = sp.quads, nstrips = sp.nstrips, lanes_out = sp.lanes_out;
+    const int nstrips = sp.nstrips, lanes_out = sp.lanes_out;
+    const bool ragged = (w & 3) != 0 ||
+                        (((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0);
     // 116 VGPRs at k = 5 -> 4 waves/SIMD; 3 at k = 7, 2 at k = 9
     BandPlan plan;
     if (!make_band_plan(h, nstrips, nframes, K <= 5 ? 4 : (K == 7 ? 3 : 2), 96, 270, 40, 0.1, &plan))
@@ -388,12 +428,19 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
         hc = hc < 0.0f ? 0.0f : (hc > 255.0f ? 255.0f : hc);  // uchar(std::clamp(.)) of the CPU path
         alpha_hi = (uint32_t)hc << 24;
     }
-    if (clamp)
-        hipLaunchKernelGGL((gauss_slide_kernel<R, true>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts, alpha_hi);
+    const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
+#define MI355_LAUNCH(CL, RG)                                                                                   \
+    hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG>), grid, block, 0, stream, d_in, d_out, w, h, nstrips,     \
+                       lanes_out, plan, wts, alpha_hi)
+    if (clamp && ragged)
+        MI355_LAUNCH(true, true);
+    else if (clamp)
+        MI355_LAUNCH(true, false);
+    else if (ragged)
+        MI355_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((gauss_slide_kernel<R, false>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, quads, h, nstrips, lanes_out, plan, wts, alpha_hi);
+        MI355_LAUNCH(false, false);
+#undef MI355_LAUNCH
     return hipGetLastError();
 }
 
@@ -402,11 +449,11 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
 bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k)
 {
     (void)h;
+    (void)w;
     if (k != 3 && k != 5 && k != 7 && k != 9)
         return false;
-    if ((w & 3) != 0)
-        return false;
-    return ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) == 0;
+    // any width: rows that are not 16-byte aligned take the RAGGED variant; pixels are dwords
+    return ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 3u) == 0;
 }
 
 hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,

@@ -36,7 +36,7 @@ struct StripPlan {
 inline StripPlan make_strip_plan(int w)
 {
     StripPlan s;
-    s.quads = w / 4;
+    s.quads = (w + 3) / 4;  // a ragged last quad counts
     s.nstrips = (s.quads + kSlideLanesOutMax - 1) / kSlideLanesOutMax;
     s.lanes_out = (s.quads + s.nstrips - 1) / s.nstrips;  // e.g. 4K: 960 quads = 16 strips x 60 lanes
     return s;

@@ -156,6 +156,34 @@ def test_gauss_opaque_fast_path_and_its_fallback(ctx, pkg, oracle, k, sigma):
     assert np.array_equal(ctx.gauss(noisy, k, sigma), tiled)
 
 
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (9, 2.5)])
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (7, 5), (75, 75), (40, 249), (33, 251), (64, 253), (131, 501),
+                                 (300, 1023), (6, 3841)])
+def test_gauss_sliding_window_ragged_widths(ctx, pkg, oracle, k, sigma, h, w):
+    """Widths that are not multiples of 4 (the reference's own images are 75x75 and 1023x819): the RAGGED
+    variant of the sliding-window kernel — unaligned rows, partial last quad — equals the tiled kernel."""
+    for alpha in (255, None):
+        img = rand_rgba(h, w, seed=h + w + k, alpha=alpha)
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        ctx.set_impl(pkg.IMPL_TILE)
+        tiled = ctx.gauss(img, k, sigma)
+        ctx.set_impl(pkg.IMPL_AUTO)
+        slide = ctx.gauss(img, k, sigma)
+        assert np.array_equal(slide, tiled)
+    if h * w <= 40000:
+        ref = oracle.gauss_rgba(img, k, sigma)
+        assert np.abs(slide.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+
+
+def test_gauss_ragged_batch_of_odd_frames(ctx, pkg, oracle):
+    """Frame stride not a multiple of 16 bytes: frames 1.. start unaligned."""
+    frames = oracle.synth_rgba(1023, 131, 3, first_frame=4, mode=1)
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(frames, 5, 1.5)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    assert np.array_equal(ctx.gauss(frames, 5, 1.5), tiled)
+
+
 def test_gauss_sliding_window_batched_multi_band(ctx, pkg, oracle):
     """Several frames, several bands per frame (h > 128), several strips (w > 248), edge strips."""
     frames = oracle.synth_rgba(1000, 300, 3, first_frame=1, mode=1)
