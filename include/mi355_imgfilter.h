@@ -65,8 +65,9 @@ const char* mi355_strerror(int code);
 int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
 
 /* Kernel selection (a tuning / test knob; results are bit-identical):
- *   AUTO — the register-resident sliding-window kernels when they apply (width % 4 == 0, 16-byte aligned
- *          buffers; Gaussian additionally k in {3,5,7,9} and FAST mode); the LDS-tiled kernels otherwise.
+ *   AUTO — the register-resident sliding-window kernels when they apply (any width; Gaussian: FAST mode and
+ *          k in {3,5,7,9} or, with an even width, {11,13,15,17}; pipeline: FAST mode, k in {3,5,7}, w >= 4,
+ *          h >= 2); the LDS-tiled kernels otherwise.
  *   TILE — always the LDS-tiled kernels. */
 #define MI355_IMPL_AUTO 0
 #define MI355_IMPL_TILE 1

@@ -47,9 +47,12 @@ __device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
                               __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
 
-template <int R, bool CLAMP>
+// RAGGED = width % 4 != 0 or unaligned buffers (see gauss_slide.hip / sobel_slide.hip): unaligned 16-byte row
+// accesses in interior strips, per-pixel clamped loads and per-byte stores in the two edge strips, and the
+// reflected column x = w of the blurred image may sit anywhere inside a lane.
+template <int R, bool CLAMP, bool RAGGED>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips,
     int lanes_out, BandPlan plan, PWeights<2 * R + 1> wts)
 {
     constexpr int K = 2 * R + 1;
@@ -65,20 +68,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const size_t frame = it.frame;
 
     const int q_lane = strip * lanes_out + lane - 1;
+    const int quads = (w + 3) >> 2;
     const int q_load = clampi(q_lane, 0, quads - 1);
     const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
-    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    const bool edge_strip = (strip == 0) || (4 * (strip * lanes_out + 63) > w);  // wave-uniform
+    const int x_lane = 4 * q_lane;
+    const int jw = w - x_lane;  // RAGGED: position of column x = w inside this lane, if 0 <= jw <= 3
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
 
     // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R
     const int nin = nout + 2 + 2 * R;
 
-    const size_t row_bytes = (size_t)quads * 16;
+    const size_t row_bytes = (size_t)w * 4;
     const uint8_t* fin = in + frame * row_bytes * h;
-    uint8_t* fout = out + frame * (size_t)quads * 4 * h;
+    uint8_t* fout = out + frame * (size_t)w * h;
     const uint32_t in_off = (uint32_t)q_load * 16u;
     const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
+    uint32_t px_off[4];  // RAGGED edge strips: the gray image clamps
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        px_off[j] = (uint32_t)clampi(x_lane + j, 0, w - 1) * 4u;
 
     float wv[K];
 #pragma unroll
@@ -87,7 +97,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
 
     auto load_row = [&](int i) -> u32x4 {
         const int y = clampi(y0 - 1 - R + min(i, nin - 1), 0, h - 1);  // gray rows: clamp-to-edge
-        return *reinterpret_cast<const u32x4*>(fin + (size_t)y * row_bytes + in_off);
+        const uint8_t* rowp = fin + (size_t)y * row_bytes;
+        if constexpr (RAGGED) {
+            u32x4 r;
+            if (edge_strip) {  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    r[j] = *reinterpret_cast<const uint32_t*>(rowp + px_off[j]);
+            } else {
+                __builtin_memcpy(&r, rowp + in_off, 16);
+            }
+            return r;
+        } else {
+            return *reinterpret_cast<const u32x4*>(rowp + in_off);
+        }
     };
 
     constexpr int PF = 3;
@@ -111,11 +134,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                     const int s3 = (u3 * K + u) % 3;  // static after unrolling
                     u32x4 p = q[u];
                     q[(u + PF) % K] = load_row(i + PF);
-                    if (edge_strip) {
-                        if (left_of_image)
-                            p = u32x4{p.x, p.x, p.x, p.x};  // gray image clamps: replicate column 0
-                        if (right_of_image)
-                            p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
+                    if constexpr (!RAGGED) {
+                        if (edge_strip) {
+                            if (left_of_image)
+                                p = u32x4{p.x, p.x, p.x, p.x};  // gray image clamps: replicate column 0
+                            if (right_of_image)
+                                p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
+                        }
                     }
                     float g[4];
 #pragma unroll
@@ -152,8 +177,23 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                         const float from_left = dppl(lb[2]);   // lane-1's pixel 2
                         if (left_of_image)
                             lb[3] = from_right;
-                        if (right_of_image)
-                            lb[0] = from_left;
+                        if constexpr (!RAGGED) {
+                            if (right_of_image)
+                                lb[0] = from_left;
+                        } else {
+                            // column x = w is pixel jw of this lane; its mirror x = w-2 is pixel jw-2 of this
+                            // lane or pixel jw+2 of the lane to the left (w >= 4 here)
+                            const float from_left3 = dppl(lb[3]);
+                            const float l0 = lb[0], l1 = lb[1];
+                            if (jw == 0)
+                                lb[0] = from_left;
+                            if (jw == 1)
+                                lb[1] = from_left3;
+                            if (jw == 2)
+                                lb[2] = l0;
+                            if (jw == 3)
+                                lb[3] = l1;
+                        }
                     }
                     // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
                     const int m = y0 - 2 + i - 2 * R;
@@ -191,9 +231,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                     const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
                     const uint32_t r = sobel_mag_fast(gx0, gy0) | (sobel_mag_fast(gx1, gy1) << 8) |
                                        (sobel_mag_fast(gx2, gy2) << 16) | (sobel_mag_fast(gx3, gy3) << 24);
-                    if (stores && m >= y0 && m < y0 + nout)
-                        __builtin_nontemporal_store(
-                            r, reinterpret_cast<uint32_t*>(fout + (size_t)m * quads * 4 + out_off));
+                    if (stores && m >= y0 && m < y0 + nout) {
+                        uint8_t* rowp = fout + (size_t)m * w;
+                        if constexpr (RAGGED) {
+                            if (edge_strip) {
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    if (x_lane + j < w)
+                                        rowp[out_off + j] = (uint8_t)(r >> (8 * j));
+                            } else {
+                                __builtin_memcpy(rowp + out_off, &r, 4);
+                            }
+                        } else {
+                            __builtin_nontemporal_store(r, reinterpret_cast<uint32_t*>(rowp + out_off));
+                        }
+                    }
                 }
             }
         }
@@ -217,12 +269,21 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
         wsum += (double)coef.h_w1d[j];
     }
     const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);
-    if (clamp)
-        hipLaunchKernelGGL((pipe_slide_kernel<R, true>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan, wts);
+    const bool ragged = (w & 3) != 0 || (reinterpret_cast<uintptr_t>(d_in) & 15u) != 0 ||
+                        (reinterpret_cast<uintptr_t>(d_out) & 3u) != 0;
+    const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
+#define MI355_LAUNCH(CL, RG)                                                                                  \
+    hipLaunchKernelGGL((pipe_slide_kernel<R, CL, RG>), grid, block, 0, stream, d_in, d_out, w, h, sp.nstrips,  \
+                       sp.lanes_out, plan, wts)
+    if (clamp && ragged)
+        MI355_LAUNCH(true, true);
+    else if (clamp)
+        MI355_LAUNCH(true, false);
+    else if (ragged)
+        MI355_LAUNCH(false, true);
     else
-        hipLaunchKernelGGL((pipe_slide_kernel<R, false>), dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan, wts);
+        MI355_LAUNCH(false, false);
+#undef MI355_LAUNCH
     return hipGetLastError();
 }
 
@@ -232,9 +293,9 @@ bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int 
 {
     if (k != 3 && k != 5 && k != 7)
         return false;
-    if ((w & 3) != 0 || h < 2)
+    if (w < 4 || h < 2)
         return false;
-    return ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 3u) == 0);
+    return (reinterpret_cast<uintptr_t>(d_in) & 3u) == 0;
 }
 
 hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,

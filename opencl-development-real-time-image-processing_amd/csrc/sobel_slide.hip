@@ -41,11 +41,16 @@ __device__ __forceinline__ float dpp_right(float v)  // lane l <- lane l+1
                               __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
 
+// RAGGED = width % 4 != 0 or unaligned buffers: interior strips use unaligned 16-byte row accesses, the two
+// edge strips address their pixels one by one through reflect-101 (which also covers the partial last quad),
+// and the output row (1 byte per pixel, width bytes long) is written byte by byte in the edge strips.
+template <bool RAGGED>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads /* w/4 */, int h, int nstrips,
-    int lanes_out, BandPlan plan)
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
+    BandPlan plan)
 {
     constexpr int K = 3;
+    const int quads = (w + 3) >> 2;
     const int lane = threadIdx.x & 63;
     SlideItem it;
     if (!slide_item(plan, nstrips, h, &it))
@@ -56,21 +61,39 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const int q_lane = strip * lanes_out + lane - 1;
     const int q_load = clampi(q_lane, 0, quads - 1);
     const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
-    const bool edge_strip = (strip == 0) || (strip * lanes_out + 62 >= quads);  // wave-uniform
+    const bool edge_strip = (strip == 0) || (4 * (strip * lanes_out + 63) > w);  // wave-uniform
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
+    const int x_lane = 4 * q_lane;
 
     const int nin = nout + 2;
 
-    const size_t row_bytes = (size_t)quads * 16;
+    const size_t row_bytes = (size_t)w * 4;
     const uint8_t* fin = in + frame * row_bytes * h;
-    uint8_t* fout = out + frame * (size_t)quads * 4 * h;  // one byte per pixel
+    uint8_t* fout = out + frame * (size_t)w * h;  // one byte per pixel
     const uint32_t in_off = (uint32_t)q_load * 16u;
     const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
+    uint32_t px_off[4];  // RAGGED edge strips: BORDER_REFLECT_101 of each pixel column (x <= w is all that is read)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        px_off[j] = (uint32_t)reflect101(clampi(x_lane + j, -1, w), w) * 4u;
 
     auto load_row = [&](int i) -> u32x4 {
         const int y = reflect101(y0 - 1 + min(i, nin - 1), h);
-        return *reinterpret_cast<const u32x4*>(fin + (size_t)y * row_bytes + in_off);
+        const uint8_t* rowp = fin + (size_t)y * row_bytes;
+        if constexpr (RAGGED) {
+            u32x4 r;
+            if (edge_strip) {  // wave-uniform
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    r[j] = *reinterpret_cast<const uint32_t*>(rowp + px_off[j]);
+            } else {
+                __builtin_memcpy(&r, rowp + in_off, 16);
+            }
+            return r;
+        } else {
+            return *reinterpret_cast<const u32x4*>(rowp + in_off);
+        }
     };
 
     constexpr int PF = 3;
@@ -89,12 +112,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
             const int i = base + u;
             u32x4 p = q[u];
             q[(u + PF) % K] = load_row(i + PF);
-            if (edge_strip) {
-                // BORDER_REFLECT_101 columns: the only halo pixel ever read is the one next to the image
-                if (left_of_image)
-                    p.w = p.y;  // x = -1  <-  x = 1   (lane holds pixels 0..3)
-                if (right_of_image)
-                    p.x = p.z;  // x = w   <-  x = w-2 (lane holds pixels w-4..w-1)
+            if constexpr (!RAGGED) {
+                if (edge_strip) {
+                    // BORDER_REFLECT_101 columns: the only halo pixel ever read is the one next to the image
+                    if (left_of_image)
+                        p.w = p.y;  // x = -1  <-  x = 1   (lane holds pixels 0..3)
+                    if (right_of_image)
+                        p.x = p.z;  // x = w   <-  x = w-2 (lane holds pixels w-4..w-1)
+                }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -121,9 +146,21 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
                                (sobel_mag_fast(gx2, gy2) << 16) |
                                (sobel_mag_fast(gx3, gy3) << 24);
             const int m = i - 2;
-            if (stores && m >= 0 && m < nout)
-                __builtin_nontemporal_store(
-                    r, reinterpret_cast<uint32_t*>(fout + (size_t)(y0 + m) * quads * 4 + out_off));
+            if (stores && m >= 0 && m < nout) {
+                uint8_t* rowp = fout + (size_t)(y0 + m) * w;
+                if constexpr (RAGGED) {
+                    if (edge_strip) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (x_lane + j < w)
+                                rowp[out_off + j] = (uint8_t)(r >> (8 * j));
+                    } else {
+                        __builtin_memcpy(rowp + out_off, &r, 4);  // rows of w bytes: any byte alignment
+                    }
+                } else {
+                    __builtin_nontemporal_store(r, reinterpret_cast<uint32_t*>(rowp + out_off));
+                }
+            }
         }
     }
 }
@@ -133,9 +170,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
 bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h)
 {
     (void)h;
-    if ((w & 3) != 0)
-        return false;
-    return ((reinterpret_cast<uintptr_t>(d_in) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 3u) == 0);
+    (void)w;
+    return (reinterpret_cast<uintptr_t>(d_in) & 3u) == 0;  // pixels are dwords; everything else is handled
 }
 
 hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes)
@@ -147,8 +183,14 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
     BandPlan plan;
     if (!make_band_plan(h, sp.nstrips, nframes, 8, 16, 16, 16, 0.0, &plan))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sobel_slide_kernel, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0, stream,
-                       d_in, d_out, sp.quads, h, sp.nstrips, sp.lanes_out, plan);
+    const bool ragged = (w & 3) != 0 || (reinterpret_cast<uintptr_t>(d_in) & 15u) != 0 ||
+                        (reinterpret_cast<uintptr_t>(d_out) & 3u) != 0;
+    if (ragged)
+        hipLaunchKernelGGL(sobel_slide_kernel<true>, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, w, h, sp.nstrips, sp.lanes_out, plan);
+    else
+        hipLaunchKernelGGL(sobel_slide_kernel<false>, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, w, h, sp.nstrips, sp.lanes_out, plan);
     return hipGetLastError();
 }
 

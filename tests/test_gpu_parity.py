@@ -227,9 +227,11 @@ def test_sobel_bit_exact(ctx, oracle, h, w):
 
 
 @pytest.mark.parametrize("h,w", [(1, 4), (2, 8), (3, 12), (40, 252), (33, 248), (7, 256), (131, 500), (300, 1920),
-                                 (5, 3840)])
+                                 (5, 3840), (1, 1), (1, 2), (2, 3), (9, 5), (75, 75), (40, 249), (33, 251),
+                                 (64, 253), (131, 501), (300, 1023), (4, 3841)])
 def test_sobel_sliding_window_kernel(ctx, pkg, oracle, h, w):
-    """sobel_slide.hip (width % 4 == 0) against the oracle and against the LDS-tiled kernel."""
+    """sobel_slide.hip (any width; RAGGED variant when width % 4 != 0) against the oracle and against the
+    LDS-tiled kernel."""
     for seed, mode in ((h + w, None), (7, 1)):
         img = rand_rgba(h, w, seed=seed) if mode is None else oracle.synth_rgba(w, h, 1, first_frame=seed, mode=1)[0]
         ctx.set_impl(pkg.IMPL_TILE)
@@ -276,7 +278,8 @@ def test_pipeline(ctx, pkg, oracle, h, w):
 
 @pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0)])
 @pytest.mark.parametrize("h,w", [(2, 4), (3, 8), (5, 12), (40, 252), (70, 248), (67, 256), (131, 500), (200, 1920),
-                                 (9, 3840)])
+                                 (9, 3840), (2, 5), (3, 6), (5, 7), (75, 75), (40, 249), (33, 250), (64, 251),
+                                 (131, 501), (200, 1023), (4, 3841)])
 def test_pipeline_sliding_window_kernel(ctx, pkg, oracle, k, sigma, h, w):
     """pipe_slide.hip (FAST, k <= 7, width % 4 == 0, h >= 2) == the LDS-tiled fused kernel == the three calls
     chained; and it stays close to the CPU chain (the Gaussian stage may differ by 1 LSB before Sobel)."""
