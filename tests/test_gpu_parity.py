@@ -462,6 +462,23 @@ def test_random_shapes_all_kernels_agree(ctx, pkg, oracle):
             assert np.abs(g_a[f].astype(np.int16) - ref.astype(np.int16)).max() <= 1, tag
 
 
+def test_8k_frame_many_strips(ctx, pkg, oracle):
+    """One 7680x4320 frame (33 strips, 45+ bands): whole-frame oracle comparison for gray and Sobel, the
+    Gaussian on three horizontal slabs (the CPU path needs ~1 s per 30 Mpixel)."""
+    w, h = 7680, 4320
+    frame = oracle.synth_rgba(w, h, 1, first_frame=11, mode=1)[0]
+    assert np.array_equal(ctx.gray1(frame), oracle.gray_rgba_1ch(frame))
+    assert np.array_equal(ctx.sobel(frame), oracle.sobel_rgba(frame))
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    g = ctx.gauss(frame, 5, 1.5)
+    for y0, y1 in ((0, 40), (2100, 2140), (4280, 4320)):
+        a, b = max(0, y0 - 2), min(h, y1 + 2)
+        ref = oracle.gauss_rgba(frame[a:b], 5, 1.5)[y0 - a:y1 - a]
+        assert np.abs(g[y0:y1].astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    p = ctx.pipeline(frame, 5, 1.5)
+    assert np.array_equal(p, ctx.sobel(ctx.gauss(ctx.gray(frame), 5, 1.5)))
+
+
 # ---- BASELINE.json full sizes: size-independent properties ------------------------------------
 def test_full_size_4k_properties(ctx, pkg, oracle):
     """4K frames: the oracle is too slow for whole frames (Gaussian ~0.3 s/frame/thread), so check
