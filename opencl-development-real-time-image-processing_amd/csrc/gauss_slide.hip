@@ -10,7 +10,7 @@
 //  * a lane owns 4 consecutive pixels (one 16-byte global_load_dwordx4 / global_store_dwordx4);
 //    a wave owns a vertical strip of up to 62 such lanes plus one halo lane on each side, and walks
 //    down a band of rows.  Every input row of the band is loaded exactly once by exactly one
-//    coalesced 1-KiB wave access; K rows are kept in flight per wave (prefetch ring in VGPRs).
+//    coalesced 1-KiB wave access; 3 rows are kept in flight per wave (prefetch ring in VGPRs).
 //  * vertical pass first, in registers: K running accumulators per lane (one per pending output
 //    row), each new row is converted once (v_cvt_f32_ubyteN) and folded into all K of them;
 //    the accumulator that just received its last tap is the finished vertical sum `v`.
@@ -18,6 +18,11 @@
 //    (wave_shr:1 / wave_shl:1) — no LDS, no barrier, no shuffle instruction.
 //  * clamp-to-edge: rows by clamping the (wave-uniform) row index; columns by replicating the edge
 //    pixel into the halo lane at load time, so the arithmetic itself has no border cases.
+//  * opaque frames (every A = 255, what cv::cvtColor produces): a band is first run on 3 channels with
+//    the constant alpha result `alpha_hi` patched in; a ballot over the loaded alphas aborts the pass
+//    and the band is redone on 4 channels, so the output never depends on which pass produced it.
+//  * RAGGED instantiation: any width and any 4-byte-aligned pointer (unaligned 16-byte interior loads,
+//    per-pixel clamped loads and predicated narrow stores in the two edge strips).
 // Algorithmic bytes: 8 B/px.  Extra traffic: halo lanes (2/62 of the loads, L2/MALL hits) and 2R
 // warm-up rows per band.  VALU: 2*K FMA per channel + 1 cvt in + 1 cvt/pack out.  Bound: HBM.
 #include <cmath>

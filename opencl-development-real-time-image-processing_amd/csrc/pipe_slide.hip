@@ -1,5 +1,6 @@
 // pipe_slide.hip — fused gray -> Gaussian -> Sobel on RGBA8 frames, register-resident sliding window,
-// FAST Gaussian arithmetic, k in {3,5,7}, width % 4 == 0, height >= 2.  gfx950 only.
+// FAST Gaussian arithmetic, k in {3,5,7}, width >= 4, height >= 2 (RAGGED instantiation when width % 4 != 0
+// or the pointers are not 16-byte aligned).  gfx950 only.
 //
 // Definition (SURVEY.md §8a "a-pipe", oracle_pipeline_rgba): exactly the composition of the three API calls
 //   g = luma(R,G,B)                                   src/Grayscale/grayscale.cpp:237

@@ -1,5 +1,6 @@
 // sobel_slide.hip — Sobel edge magnitude of RGBA8 frames, register-resident sliding window, one
-// wavefront per image strip (the shape of gauss_slide.hip).  gfx950 only; width % 4 == 0.
+// wavefront per image strip (the shape of gauss_slide.hip).  gfx950 only; any width (RAGGED
+// instantiation when width % 4 != 0 or the pointers are not 16-byte aligned).
 //
 // Replaces kernel `sobel_edge_detection` (RT/kernel/edge_base.cl:1-57) + ConvertToUChar
 // (RT/src/Controller.cpp:76-85,605) with the semantics of the reference CPU path
