@@ -184,6 +184,12 @@ int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes
 int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbytes, uint64_t index_base,
                        uint64_t* out);
 
+/* Device self-test of the two fast arithmetic forms the kernels use in place of the reference's FP64 luminance
+ * (src/Grayscale/grayscale.cpp:237) and sqrt + round + saturate (src/EdgeDetection/EdgeDetection.cpp:236-240):
+ * every one of the 2^24 colours and every (|gx|, |gy|) <= 1020 pair is compared with the exact definition on
+ * the GPU the context is bound to.  Both counts are 0 on a correct device / build.  ~1 ms. */
+int mi355_selftest(mi355_ctx* ctx, uint32_t* bad_luma, uint32_t* bad_mag);
+
 /* ---- device memory + timing helpers for hosts that do not bring their own ------------------- */
 int mi355_dev_alloc(mi355_ctx* ctx, size_t nbytes, void** d_ptr);
 int mi355_dev_free(mi355_ctx* ctx, void* d_ptr);

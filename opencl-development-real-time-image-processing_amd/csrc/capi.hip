@@ -783,6 +783,20 @@ MI355_API int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbyte
     return MI355_OK;
 }
 
+MI355_API int mi355_selftest(mi355_ctx* ctx, uint32_t* bad_luma, uint32_t* bad_mag)
+{
+    if (!ctx || !bad_luma || !bad_mag)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(ctx, launch_selftest(ctx->stream, ctx->d_acc));
+    unsigned long long v = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->d_acc, sizeof(v), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *bad_luma = (uint32_t)v;
+    *bad_mag = (uint32_t)(v >> 32);
+    return MI355_OK;
+}
+
 MI355_API int mi355_dev_alloc(mi355_ctx* ctx, size_t nbytes, void** d_ptr)
 {
     if (!ctx || !d_ptr || nbytes == 0)

@@ -52,17 +52,52 @@ __device__ __forceinline__ float luma_px_fast(uint32_t px)
     return q;
 }
 
-// min(255, round-half-even(sqrt(gx^2 + gy^2))) for integer-valued floats |gx|, |gy| <= 1020, without
-// integer fix-ups: with s = gx^2 + gy^2 (exact in fp32), round(sqrt(s)) = floor(0.5 + 0.5 * sqrt(4s - 1))
-// for s >= 1 — 4s-1 is never a perfect square and the argument of floor stays >= 1/511 away from an integer
-// for results <= 255, far more than the error of v_sqrt_f32.  Brute-forced against the exact integer form
-// for every s < 2^21, also with a +-2 ulp sqrt.  The float -> u32 conversion truncates, which is the floor.
-__device__ __forceinline__ uint32_t sobel_mag_fast(float gx, float gy)
+// Four pixels at once: the same values, but one exception test for the whole quad (the minimum of the four
+// remainders; they are >= 0 because q never exceeds S/1000), i.e. one branch per lane-quad instead of four.
+__device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4])
+{
+    float rem[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t hi = __builtin_amdgcn_udot4(p[j], 0x00000201u, 0u, false);
+        const uint32_t lo = __builtin_amdgcn_udot4(p[j], 0x00724B2Bu, 0u, false);
+        const float S = (float)((hi << 8) + lo);
+        g[j] = __builtin_floorf(__builtin_fmaf(S, 0.001f, 0.0005f));
+        rem[j] = __builtin_fmaf(g[j], -1000.0f, S);  // exact: an integer in [0, 999]
+    }
+    if (fminf(fminf(rem[0], rem[1]), fminf(rem[2], rem[3])) == 0.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (rem[j] == 0.0f)
+                g[j] = (float)luma_px(p[j]);
+    }
+}
+
+// min(255, round-half-even(sqrt(gx^2 + gy^2))) for integer-valued floats |gx|, |gy| <= 1020 — what the
+// reference computes as saturate_cast<uchar>(lrint(sqrt(s))) — in four VALU ops per pixel, packing included:
+// s = gx^2 + gy^2 is exact in fp32 (< 2^21); v_cvt_pk_u8_f32 rounds to nearest-even, saturates at 255 and
+// inserts the byte.  Rounding the 1-ulp v_sqrt_f32 instead of the exact root cannot change the result: for
+// integer s the root is never within 1/(8n+4) of a half-integer n + 1/2 (the closest, s = n^2 + n, is
+// 0.125/(n + 0.5) below it, >= 4.9e-4 for n <= 255, against an ulp of 1.5e-5), and everything above 255.5
+// saturates.  mi355_selftest checks all 1021 x 1021 (|gx|, |gy|) pairs on the device against sobel_mag_u8.
+__device__ __forceinline__ uint32_t sobel_mag_pack(float gx, float gy, uint32_t byte, uint32_t old)
 {
     const float s = __builtin_fmaf(gx, gx, gy * gy);
-    const float t = fmaxf(__builtin_fmaf(4.0f, s, -1.0f), 0.0f);
-    const float u = __builtin_amdgcn_sqrtf(t);
-    return (uint32_t)fminf(__builtin_fmaf(u, 0.5f, 0.5f), 255.5f);
+    return __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_sqrtf(s), byte, old);
+}
+
+__device__ __forceinline__ uint32_t sobel_mag_fast(float gx, float gy)
+{
+    return sobel_mag_pack(gx, gy, 0u, 0u);
+}
+
+__device__ __forceinline__ uint32_t sobel_mag_quad(const float gx[4], const float gy[4])
+{
+    uint32_t r = 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        r = sobel_mag_pack(gx[j], gy[j], (uint32_t)j, r);
+    return r;
 }
 
 __device__ __forceinline__ uint32_t gray_to_rgba(uint32_t g)

@@ -57,6 +57,7 @@ hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nf
 hipError_t launch_bgr_to_rgba(hipStream_t stream, const uint8_t* d_bgr, uint8_t* d_rgba, size_t npx);
 
 // *d_acc += order-independent checksum of nbytes at d_buf (see include/mi355_imgfilter.h)
+hipError_t launch_selftest(hipStream_t stream, unsigned long long* d_acc);
 hipError_t launch_checksum(hipStream_t stream, const uint8_t* d_buf, size_t nbytes,
                            uint64_t index_base, unsigned long long* d_acc);
 

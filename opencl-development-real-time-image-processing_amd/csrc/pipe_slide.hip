@@ -82,10 +82,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const int nin = nout + 2 + 2 * R;
 
     const size_t row_bytes = (size_t)w * 4;
-    const uint8_t* fin = in + frame * row_bytes * h;
-    uint8_t* fout = out + frame * (size_t)w * h;
-    const uint32_t in_off = (uint32_t)q_load * 16u;
-    const uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
+    const auto fin = uniform_ptr(in + frame * row_bytes * h);
+    const auto fout = uniform_ptr(out + frame * (size_t)w * h);
+    uint32_t in_off = (uint32_t)q_load * 16u;
+    uint32_t out_off = (uint32_t)(stores ? q_lane : 0) * 4u;
     uint32_t px_off[4];  // RAGGED edge strips: the gray image clamps
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -98,19 +98,20 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
 
     auto load_row = [&](int i) -> u32x4 {
         const int y = clampi(y0 - 1 - R + min(i, nin - 1), 0, h - 1);  // gray rows: clamp-to-edge
-        const uint8_t* rowp = fin + (size_t)y * row_bytes;
+        const auto rowp = fin + (size_t)y * row_bytes;  // SGPR pair; + 32-bit lane offset = saddr form
+        lane_offset_here(in_off);
         if constexpr (RAGGED) {
             u32x4 r;
             if (edge_strip) {  // wave-uniform
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    r[j] = *reinterpret_cast<const uint32_t*>(rowp + px_off[j]);
+                    r[j] = gload<uint32_t>(rowp + px_off[j]);
             } else {
-                __builtin_memcpy(&r, rowp + in_off, 16);
+                r = gload_a4<u32x4>(rowp + in_off);
             }
             return r;
         } else {
-            return *reinterpret_cast<const u32x4*>(rowp + in_off);
+            return gload<u32x4>(rowp + in_off);
         }
     };
 
@@ -144,9 +145,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                         }
                     }
                     float g[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        g[j] = luma_px_fast(p[j]);
+                    luma_quad_fast(p, g);
                     // vertical pass (canonical order): gray row i is tap j of blurred row i - j
 #pragma unroll
                     for (int j = 0; j < K; j++) {
@@ -230,10 +229,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                     const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
                     const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
                     const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
-                    const uint32_t r = sobel_mag_fast(gx0, gy0) | (sobel_mag_fast(gx1, gy1) << 8) |
-                                       (sobel_mag_fast(gx2, gy2) << 16) | (sobel_mag_fast(gx3, gy3) << 24);
+                    const float gxs[4] = {gx0, gx1, gx2, gx3}, gys[4] = {gy0, gy1, gy2, gy3};
+            const uint32_t r = sobel_mag_quad(gxs, gys);
                     if (stores && m >= y0 && m < y0 + nout) {
-                        uint8_t* rowp = fout + (size_t)m * w;
+                        const auto rowp = fout + (size_t)m * w;
+                        lane_offset_here(out_off);
                         if constexpr (RAGGED) {
                             if (edge_strip) {
 #pragma unroll
@@ -241,10 +241,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                                     if (x_lane + j < w)
                                         rowp[out_off + j] = (uint8_t)(r >> (8 * j));
                             } else {
-                                __builtin_memcpy(rowp + out_off, &r, 4);
+                                gstore_a1<uint32_t>(rowp + out_off, r);
                             }
                         } else {
-                            __builtin_nontemporal_store(r, reinterpret_cast<uint32_t*>(rowp + out_off));
+                            gstore_nt<uint32_t>(rowp + out_off, r);
                         }
                     }
                 }

@@ -96,6 +96,60 @@ inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, 
 }
 
 #ifdef __HIPCC__
+// Pins a wave-uniform row pointer in an SGPR pair.  Without it hipcc reassociates `frame + y * row_bytes +
+// lane_offset` into (frame + lane_offset) + y * row_bytes and spends a v_mov + v_mad_u64_u32 + v_add per row
+// access; with it the access uses the `saddr + 32-bit voffset` form and the row address costs no VALU at all.
+template <typename T>
+using global_ptr = __attribute__((address_space(1))) T*;  // keeps global_* (not flat_*) instructions
+
+template <typename T>
+__device__ __forceinline__ global_ptr<T> uniform_ptr(T* p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (global_ptr<T>)(((uint64_t)hi << 32) | lo);
+}
+
+// The saddr form is only selected when the 32-bit -> 64-bit extension of the lane offset happens in the basic
+// block of the access (instruction selection works per block); this makes the offset look freshly produced
+// there without emitting an instruction.
+__device__ __forceinline__ void lane_offset_here(uint32_t& off)
+{
+    asm volatile("" : "+v"(off));
+}
+
+// typed accesses through such a pointer; the *_a4 forms only assume 4-byte alignment (ragged rows)
+template <typename V>
+__device__ __forceinline__ V gload(global_ptr<const uint8_t> p)
+{
+    return *(global_ptr<const V>)p;
+}
+template <typename V>
+__device__ __forceinline__ V gload_a4(global_ptr<const uint8_t> p)
+{
+    typedef V __attribute__((aligned(4))) VA;
+    return *(global_ptr<const VA>)p;
+}
+template <typename V>
+__device__ __forceinline__ void gstore_nt(global_ptr<uint8_t> p, V v)
+{
+    __builtin_nontemporal_store(v, (global_ptr<V>)p);
+}
+template <typename V>
+__device__ __forceinline__ void gstore_a4(global_ptr<uint8_t> p, V v)
+{
+    typedef V __attribute__((aligned(4))) VA;
+    *(global_ptr<VA>)p = v;
+}
+
+template <typename V>
+__device__ __forceinline__ void gstore_a1(global_ptr<uint8_t> p, V v)
+{
+    typedef V __attribute__((aligned(1))) VA;
+    *(global_ptr<VA>)p = v;
+}
+
 // What every sliding kernel starts with: which (frame, band, strip) this wave owns.  Wave-uniform
 // (readfirstlane keeps it in SGPRs).  Returns false for the padding waves of the last block of a phase.
 struct SlideItem {

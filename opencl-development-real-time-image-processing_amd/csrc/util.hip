@@ -99,7 +99,47 @@ __global__ __launch_bounds__(kThreads) void bgr_to_rgba_kernel(const uint8_t* __
     }
 }
 
+// Exhaustive device-side check of the two fast arithmetic forms against their exact definitions:
+//   low  32 bits of *acc: colours (all 2^24) where luma_px_fast / luma_quad_fast != the FP64 formula
+//   high 32 bits of *acc: (|gx|, |gy|) pairs (all 1021^2) where the v_sqrt_f32 + v_cvt_pk_u8_f32 magnitude
+//                         != the integer form sobel_mag_u8, in any of the four byte positions
+__global__ __launch_bounds__(kThreads) void selftest_kernel(unsigned long long* __restrict__ acc)
+{
+    const uint32_t stride = gridDim.x * kThreads;
+    uint32_t bad_luma = 0, bad_mag = 0;
+    for (uint32_t c = (blockIdx.x * kThreads + threadIdx.x) * 4u; c < (1u << 24); c += stride * 4u) {
+        const u32x4 p = {c | 0xFF000000u, (c + 1u) | 0x7F000000u, c + 2u, (c + 3u) | 0x01000000u};
+        float g[4];
+        luma_quad_fast(p, g);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t want = luma_px(p[j]);
+            bad_luma += ((uint32_t)g[j] != want) + ((uint32_t)luma_px_fast(p[j]) != want);
+        }
+    }
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < 1021u * 1021u; i += stride) {
+        const int gx = (int)(i / 1021u), gy = (int)(i % 1021u);
+        const uint32_t want = sobel_mag_u8(gx, gy);
+        const float fx[4] = {(float)gx, (float)-gx, (float)gy, (float)-gy};
+        const float fy[4] = {(float)gy, (float)gy, (float)-gx, (float)gx};
+        bad_mag += (sobel_mag_quad(fx, fy) != want * 0x01010101u) + (sobel_mag_fast(fx[0], fy[0]) != want);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        bad_luma += __shfl_down(bad_luma, off, 64);
+        bad_mag += __shfl_down(bad_mag, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && (bad_luma | bad_mag))
+        atomicAdd(acc, (unsigned long long)bad_luma | ((unsigned long long)bad_mag << 32));
+}
+
 }  // namespace
+
+hipError_t launch_selftest(hipStream_t stream, unsigned long long* d_acc)
+{
+    hipLaunchKernelGGL(selftest_kernel, dim3(256 * 8), dim3(kThreads), 0, stream, d_acc);
+    return hipGetLastError();
+}
 
 hipError_t launch_bgr_to_rgba(hipStream_t stream, const uint8_t* d_bgr, uint8_t* d_rgba, size_t npx)
 {

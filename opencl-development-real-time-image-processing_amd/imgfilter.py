@@ -98,6 +98,7 @@ def load_library():
         "mi355_filter_dev": [_vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_float],
         "mi355_synth_rgba8_dev": [_vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_uint32, _ci],
         "mi355_checksum_dev": [_vp, _vp, ctypes.c_size_t, ctypes.c_uint64, _u64p],
+        "mi355_selftest": [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
         "mi355_dev_alloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
         "mi355_dev_free": [_vp, _vp],
         "mi355_copy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
@@ -299,6 +300,12 @@ class Context:
                                           ctypes.byref(out))
         _check("mi355_checksum_dev", rc, self._h)
         return out.value
+
+    def selftest(self):
+        """(bad_luma, bad_mag): exhaustive on-device check of the fast luminance / magnitude forms; (0, 0) = good."""
+        a, b = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _check("mi355_selftest", self._lib.mi355_selftest(self._h, ctypes.byref(a), ctypes.byref(b)), self._h)
+        return a.value, b.value
 
     def alloc(self, nbytes):
         p = _vp()

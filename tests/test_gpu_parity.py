@@ -513,3 +513,11 @@ def test_full_size_4k_properties(ctx, pkg, oracle):
     shifted = np.roll(frame, 64, axis=1)
     g2 = ctx.gauss(shifted, 5, 1.5)
     assert np.array_equal(g2[:, 64 + 2:-2], gauss[:, 2:-64 - 2])
+
+
+@pytest.mark.gpu
+def test_device_selftest_fast_arithmetic(ctx):
+    """All 2^24 colours (fast luminance == FP64 formula, src/Grayscale/grayscale.cpp:237) and all 1021^2 gradient
+    pairs (v_sqrt_f32 + v_cvt_pk_u8_f32 == round-half-even + saturate, src/EdgeDetection/EdgeDetection.cpp:236-240),
+    checked on the device itself."""
+    assert ctx.selftest() == (0, 0)
