@@ -190,8 +190,8 @@ __device__ __forceinline__ void hpass5_dpp(float v0, float v1, float v2, float v
 
 // What a wave needs to know about its work item, computed once in the kernel
 struct SlideLane {
-    const uint8_t* fin;
-    uint8_t* fout;
+    global_ptr<const uint8_t> fin;  // wave-uniform frame bases, pinned in SGPR pairs (slide_common.hpp)
+    global_ptr<uint8_t> fout;
     size_t row_bytes;
     uint32_t in_off, out_off;
     int y0, nout, nin, h;
@@ -211,25 +211,26 @@ template <int R, bool CLAMP, int NCH, bool RAGGED>
 __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi)
 {
     constexpr int K = 2 * R + 1;
+    uint32_t in_off = L.in_off, out_off = L.out_off;
     auto load_row = [&](int i) -> u32x4 {
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
         const int y = clampi(L.y0 - R + min(i, L.nin - 1), 0, L.h - 1);
-        const uint8_t* rowp = L.fin + (size_t)y * L.row_bytes;
+        const auto rowp = L.fin + (size_t)y * L.row_bytes;  // SGPR pair; + 32-bit lane offset = saddr form
+        if constexpr (R <= 2)  // (k = 9: the asm statements keep hipcc from unrolling the trip; k = 7: -4 %)
+            lane_offset_here(in_off);
         if constexpr (RAGGED) {
             if (L.edge_strip) {  // wave-uniform
                 u32x4 r;
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    r[j] = *reinterpret_cast<const uint32_t*>(rowp + L.px_off[j]);
+                    r[j] = gload<uint32_t>(rowp + L.px_off[j]);
                 return r;
             }
             // interior strip: all 4 pixels are inside the row, but the row is only 4-byte aligned
-            u32x4 r;
-            __builtin_memcpy(&r, rowp + L.in_off, 16);
-            return r;
+            return gload_a4<u32x4>(rowp + in_off);
         } else {
             // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
-            return *reinterpret_cast<const u32x4*>(rowp + L.in_off);
+            return gload<u32x4>(rowp + in_off);
         }
     };
 
@@ -284,63 +285,70 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                 }
             }
             const int m = i - 2 * R;  // output row that just received its last tap
-            const float* v = acc[(u + 1) % K];
-            u32x4 o;
-            if constexpr (R == 2) {
-                float hres[4][4];  // [channel][pixel]
+            // warm-up rows (m < 0) and the rows of a last partial trip (m >= nout) produce no output: skip
+            // the horizontal pass and the store with a scalar branch (m and nout live in SGPRs, so EXEC
+            // stays full inside, which the DPP reads of the horizontal pass require)
+            if (m >= 0 && m < L.nout) {
+                const float* v = acc[(u + 1) % K];
+                u32x4 o;
+                if constexpr (R == 2) {
+                    float hres[4][4];  // [channel][pixel]
 #pragma unroll
-                for (int c = 0; c < NCH; c++)
-                    hpass5_dpp(v[0 * NCH + c], v[1 * NCH + c], v[2 * NCH + c], v[3 * NCH + c], wv[0], wv[1], wv[2],
-                               wv[3], wv[4], hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
-                if constexpr (CLAMP) {
+                    for (int c = 0; c < NCH; c++)
+                        hpass5_dpp(v[0 * NCH + c], v[1 * NCH + c], v[2 * NCH + c], v[3 * NCH + c], wv[0], wv[1], wv[2],
+                                   wv[3], wv[4], hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
+                    if constexpr (CLAMP) {
 #pragma unroll
-                    for (int px = 0; px < 4; px++)
-                        o[px] = (NCH == 4) ? pack_px<true>(hres[0][px], hres[1][px], hres[2][px], hres[3][px])
-                                           : (pack_px<true>(hres[0][px], hres[1][px], hres[2][px], 0.0f) | alpha_hi);
-                } else if constexpr (NCH == 4) {
-                    cvt_pack4x4(hres, o);
-                } else {
-                    cvt_pack3x4(hres, alpha_hi, o);
-                }
-            } else {
-#pragma unroll
-                for (int px = 0; px < 4; px++) {
-                    float r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int c = 0; c < NCH; c++) {
-                        float sum = 0.0f;
-#pragma unroll
-                        for (int t = 0; t < K; t++) {
-                            const int s = px - R + t;
-                            float src;
-                            if (s < 0)
-                                src = dpp_from_left(v[(4 + s) * NCH + c]);
-                            else if (s > 3)
-                                src = dpp_from_right(v[(s - 4) * NCH + c]);
-                            else
-                                src = v[s * NCH + c];
-                            sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
-                        }
-                        r4[c] = sum;
-                    }
-                    o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
-                    if constexpr (NCH == 3)
-                        o[px] |= alpha_hi;
-                }
-            }
-            if (L.stores && m >= 0 && m < L.nout) {
-                uint8_t* rowp = L.fout + (size_t)(L.y0 + m) * L.row_bytes;
-                if constexpr (RAGGED) {
-                    if (L.edge_strip) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (L.x_lane + j < L.w)  // the last quad of a row may be partial
-                                *reinterpret_cast<uint32_t*>(rowp + L.out_off + 4 * j) = o[j];
+                        for (int px = 0; px < 4; px++)
+                            o[px] = (NCH == 4) ? pack_px<true>(hres[0][px], hres[1][px], hres[2][px], hres[3][px])
+                                               : (pack_px<true>(hres[0][px], hres[1][px], hres[2][px], 0.0f) | alpha_hi);
+                    } else if constexpr (NCH == 4) {
+                        cvt_pack4x4(hres, o);
                     } else {
-                        __builtin_memcpy(rowp + L.out_off, &o, 16);
+                        cvt_pack3x4(hres, alpha_hi, o);
                     }
                 } else {
-                    __builtin_nontemporal_store(o, reinterpret_cast<u32x4*>(rowp + L.out_off));
+#pragma unroll
+                    for (int px = 0; px < 4; px++) {
+                        float r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int c = 0; c < NCH; c++) {
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int t = 0; t < K; t++) {
+                                const int s = px - R + t;
+                                float src;
+                                if (s < 0)
+                                    src = dpp_from_left(v[(4 + s) * NCH + c]);
+                                else if (s > 3)
+                                    src = dpp_from_right(v[(s - 4) * NCH + c]);
+                                else
+                                    src = v[s * NCH + c];
+                                sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
+                            }
+                            r4[c] = sum;
+                        }
+                        o[px] = pack_px<CLAMP>(r4[0], r4[1], r4[2], r4[3]);
+                        if constexpr (NCH == 3)
+                            o[px] |= alpha_hi;
+                    }
+                }
+                if (L.stores) {
+                    const auto rowp = L.fout + (size_t)(L.y0 + m) * L.row_bytes;
+                    if constexpr (R <= 2)
+                        lane_offset_here(out_off);
+                    if constexpr (RAGGED) {
+                        if (L.edge_strip) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (L.x_lane + j < L.w)  // the last quad of a row may be partial
+                                    gstore_a4<uint32_t>(rowp + out_off + 4 * j, o[j]);
+                        } else {
+                            gstore_a4<u32x4>(rowp + out_off, o);
+                        }
+                    } else {
+                        gstore_nt<u32x4>(rowp + out_off, o);
+                    }
                 }
             }
         }
@@ -377,8 +385,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     L.w = w;
     L.x_lane = 4 * q_lane;
     L.row_bytes = (size_t)w * 4;
-    L.fin = in + it.frame * L.row_bytes * h;  // uniform base; lanes add a 32-bit offset
-    L.fout = out + it.frame * L.row_bytes * h;
+    L.fin = uniform_ptr(in + it.frame * L.row_bytes * h);  // uniform base; lanes add a 32-bit offset
+    L.fout = uniform_ptr(out + it.frame * L.row_bytes * h);
     L.in_off = (uint32_t)q_load * 16u;
     L.out_off = (uint32_t)(L.stores ? q_lane : 0) * 16u;
 #pragma unroll
@@ -410,9 +418,18 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     const int nstrips = sp.nstrips, lanes_out = sp.lanes_out;
     const bool ragged = (w & 3) != 0 ||
                         (((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0);
-    // 116 VGPRs at k = 5 -> 4 waves/SIMD; 3 at k = 7, 2 at k = 9
+    // 122 VGPRs at k = 5 -> 4 waves/SIMD; 2 at k = 7 and 9.
+    // Band height, measured on 256 x 4K frames on the two kinds of MI355X box met ("slow" boxes
+    // copy at 4.4 TB/s instead of 5.5 and prefer short bands by up to 10 %, "fast" ones hardly care):
+    //   k = 3: 16 rows (6.23 TB/s fast / 5.50 slow; adaptive tall bands 6.10 / 5.01)
+    //   k = 5: 24 rows (6.10 / 5.47; adaptive 6.10 / 5.05) — warm-up rows skip the horizontal pass, so short
+    //          bands cost little arithmetic; the general 4-channel pass alone would prefer ~64 rows (-4 % here)
+    //   k >= 7: VALU-bound at 2 waves/SIMD, the 2R warm-up rows hurt: tall adaptive bands + short-band tail
     BandPlan plan;
-    if (!make_band_plan(h, nstrips, nframes, K <= 5 ? 4 : (K == 7 ? 3 : 2), 96, 270, 40, 0.1, &plan))
+    const bool ok = (K == 3)   ? make_band_plan(h, nstrips, nframes, 5, 16, 16, 16, 0.0, &plan)
+                    : (K == 5) ? make_band_plan(h, nstrips, nframes, 4, 24, 24, 24, 0.0, &plan)
+                               : make_band_plan(h, nstrips, nframes, 2, 96, 270, 40, 0.1, &plan);
+    if (!ok)
         return hipErrorInvalidValue;
     Weights<K> wts;
     for (int j = 0; j < K; j++)

@@ -154,97 +154,104 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                         for (int e = 0; e < 4; e++)
                             acc[s][e] = (j == 0) ? wv[0] * g[e] : __builtin_fmaf(wv[j], g[e], acc[s][e]);
                     }
-                    const float* v = acc[(u + 1) % K];  // vertical sum of the blurred row that just completed
-                    // horizontal pass (canonical order), neighbour-lane taps through DPP
-                    float* lb = l[s3];
+                    // Stage gating with scalar branches (i, y0, nout live in SGPRs, EXEC stays full for the DPP
+                    // reads): the first 2R rows of a band only feed the vertical accumulators, the next two only
+                    // fill the 3-row ring, and rows past the band's last output are never stored.
+                    if (i >= 2 * R) {
+                        const float* v = acc[(u + 1) % K];  // vertical sum of the blurred row that just completed
+                        // horizontal pass (canonical order), neighbour-lane taps through DPP
+                        float* lb = l[s3];
 #pragma unroll
-                    for (int px = 0; px < 4; px++) {
-                        float sum = 0.0f;
+                        for (int px = 0; px < 4; px++) {
+                            float sum = 0.0f;
 #pragma unroll
-                        for (int t = 0; t < K; t++) {
-                            const int s = px - R + t;
-                            const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
-                            sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
-                        }
-                        if constexpr (CLAMP)
-                            sum = fminf(sum, 255.0f);
-                        const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
-                        lb[px] = (float)lut[bq];            // luma(b,b,b) re-applied
-                    }
-                    if (edge_strip) {
-                        // the blurred image reflects (BORDER_REFLECT_101): x = -1 <- x = 1, x = w <- x = w-2
-                        const float from_right = dppr(lb[1]);  // lane+1's pixel 1
-                        const float from_left = dppl(lb[2]);   // lane-1's pixel 2
-                        if (left_of_image)
-                            lb[3] = from_right;
-                        if constexpr (!RAGGED) {
-                            if (right_of_image)
-                                lb[0] = from_left;
-                        } else {
-                            // column x = w is pixel jw of this lane; its mirror x = w-2 is pixel jw-2 of this
-                            // lane or pixel jw+2 of the lane to the left (w >= 4 here)
-                            const float from_left3 = dppl(lb[3]);
-                            const float l0 = lb[0], l1 = lb[1];
-                            if (jw == 0)
-                                lb[0] = from_left;
-                            if (jw == 1)
-                                lb[1] = from_left3;
-                            if (jw == 2)
-                                lb[2] = l0;
-                            if (jw == 3)
-                                lb[3] = l1;
-                        }
-                    }
-                    // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
-                    const int m = y0 - 2 + i - 2 * R;
-                    const float* lm = l[(s3 + 2) % 3];  // blurred row m
-                    const float* lt = l[(s3 + 1) % 3];  // blurred row m - 1
-                    // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the
-                    // bottom row (h) is row h-2 = the top row.  Wave-uniform and rare: a branch, not selects.
-                    const float* top = lt;
-                    const float* bot = lb;
-                    float cs[4], cd[4];
-                    if (__builtin_expect(m == 0 || m == h - 1, 0)) {
-                        // keeps this a real (never-taken) branch: hipcc otherwise if-converts both arms into
-                        // 8 v_cndmask per row on the common path
-                        asm volatile("; first / last image row");
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const float tv = (m == 0) ? lb[j] : lt[j];
-                            const float bv = (m == h - 1) ? lt[j] : lb[j];
-                            cs[j] = __builtin_fmaf(2.0f, lm[j], tv) + bv;
-                            cd[j] = bv - tv;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            cs[j] = __builtin_fmaf(2.0f, lm[j], top[j]) + bot[j];
-                            cd[j] = bot[j] - top[j];
-                        }
-                    }
-                    const float csl = dppl(cs[3]), csr = dppr(cs[0]);
-                    const float cdl = dppl(cd[3]), cdr = dppr(cd[0]);
-                    const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
-                    const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
-                    const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
-                    const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
-                    const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
-                    const float gxs[4] = {gx0, gx1, gx2, gx3}, gys[4] = {gy0, gy1, gy2, gy3};
-            const uint32_t r = sobel_mag_quad(gxs, gys);
-                    if (stores && m >= y0 && m < y0 + nout) {
-                        const auto rowp = fout + (size_t)m * w;
-                        lane_offset_here(out_off);
-                        if constexpr (RAGGED) {
-                            if (edge_strip) {
-#pragma unroll
-                                for (int j = 0; j < 4; j++)
-                                    if (x_lane + j < w)
-                                        rowp[out_off + j] = (uint8_t)(r >> (8 * j));
-                            } else {
-                                gstore_a1<uint32_t>(rowp + out_off, r);
+                            for (int t = 0; t < K; t++) {
+                                const int s = px - R + t;
+                                const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
+                                sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
                             }
-                        } else {
-                            gstore_nt<uint32_t>(rowp + out_off, r);
+                            if constexpr (CLAMP)
+                                sum = fminf(sum, 255.0f);
+                            const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
+                            lb[px] = (float)lut[bq];            // luma(b,b,b) re-applied
+                        }
+                        if (edge_strip) {
+                            // the blurred image reflects (BORDER_REFLECT_101): x = -1 <- x = 1, x = w <- x = w-2
+                            const float from_right = dppr(lb[1]);  // lane+1's pixel 1
+                            const float from_left = dppl(lb[2]);   // lane-1's pixel 2
+                            if (left_of_image)
+                                lb[3] = from_right;
+                            if constexpr (!RAGGED) {
+                                if (right_of_image)
+                                    lb[0] = from_left;
+                            } else {
+                                // column x = w is pixel jw of this lane; its mirror x = w-2 is pixel jw-2 of this
+                                // lane or pixel jw+2 of the lane to the left (w >= 4 here)
+                                const float from_left3 = dppl(lb[3]);
+                                const float l0 = lb[0], l1 = lb[1];
+                                if (jw == 0)
+                                    lb[0] = from_left;
+                                if (jw == 1)
+                                    lb[1] = from_left3;
+                                if (jw == 2)
+                                    lb[2] = l0;
+                                if (jw == 3)
+                                    lb[3] = l1;
+                            }
+                        }
+                        // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
+                        const int m = y0 - 2 + i - 2 * R;
+                        if (m >= y0 && m < y0 + nout) {
+                            const float* lm = l[(s3 + 2) % 3];  // blurred row m
+                            const float* lt = l[(s3 + 1) % 3];  // blurred row m - 1
+                            // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the
+                            // bottom row (h) is row h-2 = the top row.  Wave-uniform and rare: a branch, not selects.
+                            const float* top = lt;
+                            const float* bot = lb;
+                            float cs[4], cd[4];
+                            if (__builtin_expect(m == 0 || m == h - 1, 0)) {
+                                // keeps this a real (never-taken) branch: hipcc otherwise if-converts both arms into
+                                // 8 v_cndmask per row on the common path
+                                asm volatile("; first / last image row");
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    const float tv = (m == 0) ? lb[j] : lt[j];
+                                    const float bv = (m == h - 1) ? lt[j] : lb[j];
+                                    cs[j] = __builtin_fmaf(2.0f, lm[j], tv) + bv;
+                                    cd[j] = bv - tv;
+                                }
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; j++) {
+                                    cs[j] = __builtin_fmaf(2.0f, lm[j], top[j]) + bot[j];
+                                    cd[j] = bot[j] - top[j];
+                                }
+                            }
+                            const float csl = dppl(cs[3]), csr = dppr(cs[0]);
+                            const float cdl = dppl(cd[3]), cdr = dppr(cd[0]);
+                            const float gx0 = cs[1] - csl, gx1 = cs[2] - cs[0], gx2 = cs[3] - cs[1], gx3 = csr - cs[2];
+                            const float gy0 = __builtin_fmaf(2.0f, cd[0], cdl) + cd[1];
+                            const float gy1 = __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2];
+                            const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
+                            const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
+                            const float gxs[4] = {gx0, gx1, gx2, gx3}, gys[4] = {gy0, gy1, gy2, gy3};
+                    const uint32_t r = sobel_mag_quad(gxs, gys);
+                            if (stores) {
+                                const auto rowp = fout + (size_t)m * w;
+                                lane_offset_here(out_off);
+                                if constexpr (RAGGED) {
+                                    if (edge_strip) {
+#pragma unroll
+                                        for (int j = 0; j < 4; j++)
+                                            if (x_lane + j < w)
+                                                rowp[out_off + j] = (uint8_t)(r >> (8 * j));
+                                    } else {
+                                        gstore_a1<uint32_t>(rowp + out_off, r);
+                                    }
+                                } else {
+                                    gstore_nt<uint32_t>(rowp + out_off, r);
+                                }
+                            }
                         }
                     }
                 }
@@ -259,9 +266,13 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
 {
     constexpr int K = 2 * R + 1;
     const StripPlan sp = make_strip_plan(w);
-    // ~60 VGPRs -> 8 waves/SIMD; 2R+2 warm-up rows per band are pure overhead for this VALU-heavy kernel
+    // ~64 VGPRs -> 8 waves/SIMD.  Short bands win although every band spends 2R+2 warm-up rows: measured on
+    // 256 x 4K frames, k = 5 (two kinds of MI355X box): 24 rows 4.6-4.8 TB/s, 48 rows 4.4-4.6,
+    // 108 rows (the former adaptive plan) 4.1-4.4.  The kernel is not VALU-bound (removing 15 % of its VALU
+    // instructions changed nothing), short bands keep the rows that are in flight close together in memory.
     BandPlan plan;
-    if (!make_band_plan(h, sp.nstrips, nframes, 8, 64, 270, 32, 0.1, &plan))
+    constexpr int kRows = (R == 1) ? 16 : (R == 2 ? 24 : 40);
+    if (!make_band_plan(h, sp.nstrips, nframes, 8, kRows, kRows, kRows, 0.0, &plan))
         return hipErrorInvalidValue;
     PWeights<K> wts;
     double wsum = 0.0;

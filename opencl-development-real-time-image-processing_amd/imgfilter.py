@@ -62,9 +62,11 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(_LIB):
-        raise Mi355Error("load_library", -1, "%s is missing: run __graft_entry__.build()" % _LIB)
-    lib = ctypes.CDLL(_LIB)
+    # MI355_IMGFILTER_LIB: another build of the same library (A/B timing of kernel changes, tools/ab.sh)
+    path = os.environ.get("MI355_IMGFILTER_LIB", _LIB)
+    if not os.path.exists(path):
+        raise Mi355Error("load_library", -1, "%s is missing: run __graft_entry__.build()" % path)
+    lib = ctypes.CDLL(path)
     sig = {
         "mi355_device_count": [ctypes.POINTER(_ci)],
         "mi355_ctx_create": [_ci, ctypes.POINTER(_vp)],
@@ -107,7 +109,12 @@ def load_library():
         "mi355_timer_end": [_vp, _f32p],
     }
     for name, args in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if path == _LIB:
+                raise
+            continue  # an older build under MI355_IMGFILTER_LIB
         fn.argtypes = args
         fn.restype = _ci
     lib.mi355_strerror.argtypes = [_ci]
