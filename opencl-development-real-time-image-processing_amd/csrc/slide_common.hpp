@@ -153,7 +153,7 @@ __device__ __forceinline__ void gstore_a1(global_ptr<uint8_t> p, V v)
 // What every sliding kernel starts with: which (frame, band, strip) this wave owns.  Wave-uniform
 // (readfirstlane keeps it in SGPRs).  Returns false for the padding waves of the last block of a phase.
 struct SlideItem {
-    int strip, y0, nout;
+    int strip, band, y0, nout;
     size_t frame;
 };
 
@@ -171,6 +171,7 @@ __device__ __forceinline__ bool slide_item(const BandPlan& plan, int nstrips, in
     it->strip = work % nstrips;
     const int band = (work / nstrips) % nbands;
     it->frame = work / ((uint32_t)nstrips * nbands);
+    it->band = band;
     it->y0 = (tail ? plan.y_split : 0) + band * band_rows;
     it->nout = min(band_rows, (tail ? h : plan.y_split) - it->y0);
     return true;

@@ -79,8 +79,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     for (int j = 0; j < 4; j++)
         px_off[j] = (uint32_t)reflect101(clampi(x_lane + j, -1, w), w) * 4u;
 
+    // Odd bands walk UP (the stencil is symmetric under a vertical flip: gy only changes sign, and it is squared;
+    // all arithmetic is exact, so the bits do not change).  A down-walking band and the up-walking band below it
+    // then read their two shared boundary rows at the same moment — the end of both walks — and the second reader
+    // hits L2 instead of HBM; likewise the up-walking band and the down-walking one below it at their start.
+    const bool up = (it.band & 1) != 0;
     auto load_row = [&](int i) -> u32x4 {
-        const int y = reflect101(y0 - 1 + min(i, nin - 1), h);
+        const int ii = min(i, nin - 1);
+        const int y = reflect101(up ? y0 + nout - ii : y0 - 1 + ii, h);
         const auto rowp = fin + (size_t)y * row_bytes;  // SGPR pair; + 32-bit lane offset = saddr form
         lane_offset_here(in_off);
         if constexpr (RAGGED) {
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
             const uint32_t r = sobel_mag_quad(gxs, gys);
             const int m = i - 2;
             if (stores && m >= 0 && m < nout) {
-                const auto rowp = fout + (size_t)(y0 + m) * w;
+                const auto rowp = fout + (size_t)(up ? y0 + nout - 1 - m : y0 + m) * w;
                 lane_offset_here(out_off);
                 if constexpr (RAGGED) {
                     if (edge_strip) {

@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B timing of two builds of libmi355_imgfilter.so on ONE box (boxes differ by +-10 %, so numbers from
 # different gpurun calls are not comparable).  Usage: tools/ab.sh <libA.so> <rounds> -- <bench args> [-- <bench args> ...]
-# Alternates A, B (B = the in-tree build) `rounds` times per argument set; prints achieved GB/s per run.
+# <libA.so> may be a comma-separated list of builds (tools/build_variant.sh); each is labelled by its file name.
+# Alternates the listed builds and B (= the in-tree build) `rounds` times per argument set; prints achieved GB/s.
 A=$1; ROUNDS=$2; shift 2
 [ "$1" = "--" ] && shift
 sets=(); cur=""
@@ -18,7 +19,7 @@ one() {  # $1 = label, $2 = lib or "", rest = args
 for s in "${sets[@]}"; do
   echo "== $s"
   for r in $(seq "$ROUNDS"); do
-    one A "$A" $s
+    for lib in ${A//,/ }; do one "$(basename $lib .so)" "$lib" $s; done
     one B "" $s
   done
 done
