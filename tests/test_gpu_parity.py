@@ -521,3 +521,43 @@ def test_device_selftest_fast_arithmetic(ctx):
     pairs (v_sqrt_f32 + v_cvt_pk_u8_f32 == round-half-even + saturate, src/EdgeDetection/EdgeDetection.cpp:236-240),
     checked on the device itself."""
     assert ctx.selftest() == (0, 0)
+
+
+_BAND_PLAN_SCRIPT = r"""
+import sys, hashlib, numpy as np
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as e
+pkg = e.load_package()
+rng = np.random.default_rng(99)
+h = hashlib.sha256()
+with pkg.Context(0) as ctx:
+    for (n, hh, ww) in [(3, 131, 500), (2, 97, 1023), (1, 300, 252)]:
+        x = rng.integers(0, 256, (n, hh, ww, 4), dtype=np.uint8)
+        y = x.copy(); y[..., 3] = 255
+        for img in (x, y):
+            for k, s in [(3, 0.8), (5, 1.5), (7, 2.0), (9, 2.5)]:
+                h.update(ctx.gauss(img, k, s).tobytes())
+            for k, s in [(3, 0.8), (5, 1.5), (7, 2.0)]:
+                h.update(ctx.pipeline(img, k, s).tobytes())
+            h.update(ctx.sobel(img).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_results_do_not_depend_on_the_band_plan():
+    """The sliding-window kernels cut frames into bands whose height is a tuning choice (slide_common.hpp) and
+    the Sobel kernel walks odd bands upward: outputs must be the same bytes for every plan.  The plan is fixed per
+    process (MI355_TUNE_* are read once), hence one short child process per plan."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for plan in ({}, {"MI355_TUNE_BAND_ROWS": "1"}, {"MI355_TUNE_BAND_ROWS": "7"},
+                 {"MI355_TUNE_BAND_ROWS": "50", "MI355_TUNE_TAIL_ROWS": "3", "MI355_TUNE_TAIL_FRAC": "0.3"}):
+        env = dict(os.environ, **plan)
+        out = subprocess.run([sys.executable, "-c", _BAND_PLAN_SCRIPT, root], env=env, capture_output=True,
+                             text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[tuple(sorted(plan.items()))] = out.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
