@@ -38,6 +38,8 @@ struct mi355_ctx {
     void* d_out = nullptr;
     size_t d_out_cap = 0;
     unsigned long long* d_acc = nullptr;
+    void* d_flags = nullptr;  // per-work-item flags of the two-kernel Gaussian (gauss_wide.hip), pooled
+    size_t d_flags_cap = 0;
     // streamed path: copy streams, per-slot events and device slots (created on first use)
     static constexpr int kSlots = 3;
     hipStream_t s_h2d = nullptr, s_d2h = nullptr;
@@ -240,9 +242,17 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
     case MI355_FILTER_GRAY1:
         e = launch_gray(ctx->stream, in, out, w, h, nframes, true);
         break;
-    case MI355_FILTER_GAUSS:
-        e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->impl);
+    case MI355_FILTER_GAUSS: {
+        const size_t nflags = gauss_flag_items(in, out, w, h, nframes, coef->k, exact, ctx->impl);
+        if (nflags) {
+            rc = ensure(ctx, &ctx->d_flags, &ctx->d_flags_cap, nflags * sizeof(uint32_t));
+            if (rc != MI355_OK)
+                return rc;
+        }
+        e = launch_gauss(ctx->stream, in, out, w, h, nframes, *coef, exact, ctx->impl,
+                         static_cast<uint32_t*>(ctx->d_flags));
         break;
+    }
     case MI355_FILTER_SOBEL:
         e = launch_sobel(ctx->stream, in, out, w, h, nframes, ctx->impl);
         break;
@@ -408,6 +418,8 @@ MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
         (void)hipFree(ctx->d_out);
     if (ctx->d_acc)
         (void)hipFree(ctx->d_acc);
+    if (ctx->d_flags)
+        (void)hipFree(ctx->d_flags);
     for (int i = 0; i < mi355_ctx::kSlots; i++) {
         if (ctx->slot_in[i])
             (void)hipFree(ctx->slot_in[i]);

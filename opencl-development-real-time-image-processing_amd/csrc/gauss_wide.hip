@@ -5,8 +5,15 @@
 //  * a lane owns 2 consecutive pixels (one 8-byte load); K running accumulators x 8 floats per lane;
 //  * a wave owns a strip of 64 - 2H lanes plus H = ceil(R/2) halo lanes per side;
 //  * horizontal taps reach up to R pixels = H lanes away, beyond one DPP shift: the finished vertical sums of
-//    a row go through a wave-private 2-KiB LDS row (two ds_write_b128 per lane, K+1 ds_read_b128 back); LDS
-//    operations of one wave execute in order, so no barrier is involved.
+//    a row go through a wave-private LDS row (two ds_write_b128 per lane, K+1 ds_read_b128 back at immediate
+//    offsets from one per-lane base; the row is padded by R entries per side so that the halo lanes' windows
+//    need no clamping — they read padding, and halo lanes never store); LDS operations of one wave execute in
+//    order, so no barrier is involved.
+//  * TWO kernels, because registers are allocated per kernel: the opaque pass (3 channels, see gauss_slide.hip)
+//    needs 6 K accumulators, the general one 8 K — at k = 17 that is the difference between 2 waves per SIMD
+//    and 1.  Kernel A runs the opaque pass and leaves one flag per work item (0 = band done, 1 = an alpha != 255
+//    turned up); kernel B, launched right behind it on the same stream, redoes the flagged bands with 4 channels
+//    and exits at once everywhere else.
 // The inner loop is unrolled K times (static accumulator slots): ~2 KB of code per row, 34 KB at k = 17.
 // Bound: FP32 VALU (2K FMA per channel-pixel); algorithmic bytes 8 B/px.
 #include <cmath>
@@ -30,7 +37,7 @@ struct WWeights {
 struct WideLane {
     const uint8_t* fin;
     uint8_t* fout;
-    f32x4* vr;  // this wave's 128-entry LDS row
+    f32x4* vr;  // this wave's LDS row: entry R + p holds pixel p of the strip (p = 0..127), R padding entries per side
     size_t row_bytes;
     uint32_t in_off, out_off;
     int y0, nout, nin, h, lane;
@@ -54,8 +61,9 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
         q[u] = load_row(u);
 
     float acc[K][2 * NCH] = {};
-    // window base for the horizontal pass: output pixel e of this lane reads pixels 2*lane + e - R + t
-    const int win0 = 2 * L.lane - R;
+    // horizontal pass: output pixel e of this lane reads strip pixels 2*lane + e - R + t = row entries
+    // 2*lane + e + t, t = 0..K-1: one base pointer per lane, immediate offsets per tap
+    const f32x4* win = L.vr + 2 * L.lane;
 
     for (int base = 0; base < L.nin; base += K) {
 #pragma unroll
@@ -91,13 +99,23 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
             const int m = i - 2 * R;
             if (m >= 0) {  // wave-uniform: the first 2R rows of a band finish no output row
                 const float* v = acc[(u + 1) % K];
-                L.vr[2 * L.lane] = f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f};
-                L.vr[2 * L.lane + 1] = f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f};
+                L.vr[R + 2 * L.lane] = f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f};
+                L.vr[R + 2 * L.lane + 1] = f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f};
+                // The other 63 lanes read these entries below.  The hardware executes a wave's LDS operations in
+                // order, but the compiler knows nothing of lanes: without a release/acquire pair at wavefront
+                // scope it may treat the stores as thread-private (it deleted 20 of the 22 in one build of this
+                // kernel, forwarding the values to this lane's own two reads).  The fences emit no instruction.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // horizontal pass: K+1 window values feed the two outputs (tap t of output e is value t+e)
                 float o0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, o1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int t = 0; t <= K; t++) {
-                    const f32x4 a = L.vr[clampi(win0 + t, 0, 127)];
+                    // entries R and R+1 of the window are this lane's own two pixels: no LDS read for them
+                    const f32x4 a = (t == R)       ? f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f}
+                                    : (t == R + 1) ? f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f}
+                                                   : win[t];
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         if (t < K)
@@ -106,16 +124,19 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
                             o1[c] = (t == 1) ? wv[0] * a[c] : __builtin_fmaf(wv[t - 1], a[c], o1[c]);
                     }
                 }
+                // (and the next row's stores must stay behind this row's reads)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
                 if (L.stores && m < L.nout) {
+                    // uchar(clamp(v, 0, 255)) = floor, then v_cvt_pk_u8_f32 (exact on integers, saturates both ways,
+                    // inserts the byte): 2 ops per channel instead of max + min + cvt + shift + or
                     u32x2 r;
-                    r.x = f2u8(o0[0]) | (f2u8(o0[1]) << 8) | (f2u8(o0[2]) << 16);
-                    r.y = f2u8(o1[0]) | (f2u8(o1[1]) << 8) | (f2u8(o1[2]) << 16);
-                    if constexpr (NCH == 4) {
-                        r.x |= f2u8(o0[3]) << 24;
-                        r.y |= f2u8(o1[3]) << 24;
-                    } else {
-                        r.x |= alpha_hi;
-                        r.y |= alpha_hi;
+                    r.x = (NCH == 4) ? 0u : alpha_hi;
+                    r.y = r.x;
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        r.x = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o0[c]), (uint32_t)c, r.x);
+                        r.y = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_floorf(o1[c]), (uint32_t)c, r.y);
                     }
                     __builtin_nontemporal_store(
                         r, reinterpret_cast<u32x2*>(L.fout + (size_t)(L.y0 + m) * L.row_bytes + L.out_off));
@@ -126,17 +147,22 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
     return true;
 }
 
-template <int R>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_wide_kernel(
+// NCH = 3: kernel A (opaque pass, writes flags[work]); NCH = 4: kernel B (redoes the bands kernel A flagged)
+template <int R, int NCH>
+__global__ __launch_bounds__(kWavesPerBlock * 64, (NCH == 3 && R <= 6) ? 3 : 2) void gauss_wide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int pairs /* w/2 */, int h, int nstrips,
-    int lanes_out, BandPlan plan, WWeights<2 * R + 1> wts, uint32_t alpha_hi)
+    int lanes_out, BandPlan plan, WWeights<2 * R + 1> wts, uint32_t alpha_hi, uint32_t* __restrict__ flags)
 {
     constexpr int K = 2 * R + 1;
     constexpr int H = (R + 1) / 2;  // halo lanes per side (2 px each)
-    __shared__ f32x4 vrow[kWavesPerBlock][128];
+    __shared__ f32x4 vrow[kWavesPerBlock][128 + 2 * R];
     SlideItem it;
     if (!slide_item(plan, nstrips, h, &it))
         return;
+    if constexpr (NCH == 4) {
+        if (flags[it.work] == 0)  // wave-uniform: kernel A finished this band
+            return;
+    }
     WideLane L;
     L.vr = vrow[threadIdx.x >> 6];
     L.lane = threadIdx.x & 63;
@@ -163,23 +189,32 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_wide_kernel(
     for (int j = 0; j < K; j++)
         wv[j] = wts.w[j];
 
-    // opaque fast path first, full redo of the band if any alpha != 255 shows up (gauss_slide.hip)
-    if (!gauss_wide_band<R, 3>(L, wv, alpha_hi))
-        gauss_wide_band<R, 4>(L, wv, alpha_hi);
+    const bool done = gauss_wide_band<R, NCH>(L, wv, alpha_hi);
+    if constexpr (NCH == 3) {
+        if (L.lane == 0)
+            flags[it.work] = done ? 0u : 1u;
+    }
+}
+
+template <int R>
+bool wide_plan(int w, int h, int nframes, int& pairs, int& nstrips, int& lanes_out, BandPlan* plan)
+{
+    constexpr int H = (R + 1) / 2;
+    pairs = w / 2;
+    const int lanes_max = 64 - 2 * H;
+    nstrips = (pairs + lanes_max - 1) / lanes_max;
+    lanes_out = (pairs + nstrips - 1) / nstrips;
+    return make_band_plan(h, nstrips, nframes, 2, 128, 360, 48, 0.1, plan);
 }
 
 template <int R>
 hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
-                    const GaussCoef& coef)
+                    const GaussCoef& coef, uint32_t* d_flags)
 {
     constexpr int K = 2 * R + 1;
-    constexpr int H = (R + 1) / 2;
-    const int pairs = w / 2;
-    const int lanes_max = 64 - 2 * H;
-    const int nstrips = (pairs + lanes_max - 1) / lanes_max;
-    const int lanes_out = (pairs + nstrips - 1) / nstrips;
+    int pairs, nstrips, lanes_out;
     BandPlan plan;
-    if (!make_band_plan(h, nstrips, nframes, 2, 128, 360, 48, 0.1, &plan))
+    if (!d_flags || !wide_plan<R>(w, h, nframes, pairs, nstrips, lanes_out, &plan))
         return hipErrorInvalidValue;
     WWeights<K> wts;
     for (int j = 0; j < K; j++)
@@ -193,8 +228,11 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
         hc = std::fmaf(wts.w[t], vc, hc);
     hc = hc < 0.0f ? 0.0f : (hc > 255.0f ? 255.0f : hc);
     const uint32_t alpha_hi = (uint32_t)hc << 24;
-    hipLaunchKernelGGL(gauss_wide_kernel<R>, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                       stream, d_in, d_out, pairs, h, nstrips, lanes_out, plan, wts, alpha_hi);
+    const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
+    hipLaunchKernelGGL((gauss_wide_kernel<R, 3>), grid, block, 0, stream, d_in, d_out, pairs, h, nstrips, lanes_out,
+                       plan, wts, alpha_hi, d_flags);
+    hipLaunchKernelGGL((gauss_wide_kernel<R, 4>), grid, block, 0, stream, d_in, d_out, pairs, h, nstrips, lanes_out,
+                       plan, wts, alpha_hi, d_flags);
     return hipGetLastError();
 }
 
@@ -210,14 +248,29 @@ bool gauss_wide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int 
     return ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 7u) == 0;
 }
 
+size_t gauss_wide_flag_items(int w, int h, int nframes, int k)
+{
+    int pairs, nstrips, lanes_out;
+    BandPlan plan;
+    bool ok = false;
+    switch (k) {
+    case 11: ok = wide_plan<5>(w, h, nframes, pairs, nstrips, lanes_out, &plan); break;
+    case 13: ok = wide_plan<6>(w, h, nframes, pairs, nstrips, lanes_out, &plan); break;
+    case 15: ok = wide_plan<7>(w, h, nframes, pairs, nstrips, lanes_out, &plan); break;
+    case 17: ok = wide_plan<8>(w, h, nframes, pairs, nstrips, lanes_out, &plan); break;
+    default: break;
+    }
+    return ok ? (size_t)plan.nwork_a + plan.nwork_b : 0;
+}
+
 hipError_t launch_gauss_wide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
-                             const GaussCoef& coef)
+                             const GaussCoef& coef, uint32_t* d_flags)
 {
     switch (coef.k) {
-    case 11: return launch_r<5>(stream, d_in, d_out, w, h, nframes, coef);
-    case 13: return launch_r<6>(stream, d_in, d_out, w, h, nframes, coef);
-    case 15: return launch_r<7>(stream, d_in, d_out, w, h, nframes, coef);
-    case 17: return launch_r<8>(stream, d_in, d_out, w, h, nframes, coef);
+    case 11: return launch_r<5>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 13: return launch_r<6>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 15: return launch_r<7>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 17: return launch_r<8>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     default: return hipErrorInvalidValue;
     }
 }

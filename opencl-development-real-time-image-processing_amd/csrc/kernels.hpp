@@ -20,9 +20,13 @@ struct GaussCoef {
 hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                        int nframes, bool one_channel);
 
-// impl: 0 = choose (sliding window when supported), 1 = force the LDS-tiled kernel
+// impl: 0 = choose (sliding window when supported), 1 = force the LDS-tiled kernel.
+// d_flags: device scratch of gauss_flag_items(...) uint32 (one per work item of the two-kernel opaque/fallback
+// scheme, see gauss_wide.hip); may be null when that returns 0.
+size_t gauss_flag_items(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, int k, bool exact,
+                        int impl);
 hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                        int nframes, const GaussCoef& coef, bool exact, int impl);
+                        int nframes, const GaussCoef& coef, bool exact, int impl, uint32_t* d_flags);
 
 // the two implementations launch_gauss chooses between
 hipError_t launch_gauss_tile(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
@@ -35,8 +39,9 @@ hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
 
 // register-resident kernel for k = 11..17 (2 px per lane, LDS row exchange); width % 2 == 0, 8-byte aligned
 bool gauss_wide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+size_t gauss_wide_flag_items(int w, int h, int nframes, int k);
 hipError_t launch_gauss_wide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
-                             const GaussCoef& coef);
+                             const GaussCoef& coef, uint32_t* d_flags);
 
 // impl: 0 = choose (sliding window when width % 4 == 0 and buffers aligned), 1 = force the LDS-tiled kernel
 hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,

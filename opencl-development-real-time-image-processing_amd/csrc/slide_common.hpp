@@ -154,6 +154,7 @@ __device__ __forceinline__ void gstore_a1(global_ptr<uint8_t> p, V v)
 // (readfirstlane keeps it in SGPRs).  Returns false for the padding waves of the last block of a phase.
 struct SlideItem {
     int strip, band, y0, nout;
+    uint32_t work;  // index of this work item in [0, nwork_a + nwork_b): one flag slot per item
     size_t frame;
 };
 
@@ -168,6 +169,7 @@ __device__ __forceinline__ bool slide_item(const BandPlan& plan, int nstrips, in
         return false;
     const int nbands = tail ? plan.nbands_b : plan.nbands_a;
     const int band_rows = tail ? plan.rows_b : plan.rows_a;
+    it->work = tail ? plan.nwork_a + work : work;
     it->strip = work % nstrips;
     const int band = (work / nstrips) % nbands;
     it->frame = work / ((uint32_t)nstrips * nbands);
