@@ -356,10 +356,15 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
     return true;
 }
 
-template <int R, bool CLAMP, bool RAGGED>
+// MODE 0: one kernel, opaque pass then (if an alpha != 255 turns up) the general pass — k = 3, 5, where both fit
+// in 4 waves/SIMD.  MODE 3 / MODE 4: the two passes as two kernels launched back to back (k = 7, 9): registers
+// are allocated per kernel, and the opaque pass alone needs 139 instead of 173 VGPRs at k = 7 (3 waves/SIMD
+// instead of 2).  Kernel MODE 3 leaves flags[work] = 0 (band done) or 1; kernel MODE 4 redoes the flagged bands
+// and exits at once everywhere else (gauss_wide.hip does the same).
+template <int R, bool CLAMP, bool RAGGED, int MODE>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
-    BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi)
+    BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi, uint32_t* __restrict__ flags)
 {
     const int quads = (w + 3) >> 2;  // RAGGED: the last quad of a row may hold fewer than 4 pixels
     constexpr int K = 2 * R + 1;
@@ -367,6 +372,10 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     SlideItem it;
     if (!slide_item(plan, nstrips, h, &it))
         return;
+    if constexpr (MODE == 4) {
+        if (flags[it.work] == 0)  // wave-uniform
+            return;
+    }
     const int strip = it.strip;
 
     const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
@@ -405,32 +414,48 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     // RT/src/ProgramHandler.cpp:127): with every alpha tap 255 the blurred alpha is one constant byte, which
     // the host computes with the same float chain (std::fmaf) — 25 % of the arithmetic gone, same bits.
     // A band that meets any other alpha value is redone in full.
-    if (!gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi))
+    if constexpr (MODE == 0) {
+        if (!gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi))
+            gauss_slide_band<R, CLAMP, 4, RAGGED>(L, wv, alpha_hi);
+    } else if constexpr (MODE == 3) {
+        const bool done = gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi);
+        if (lane == 0)
+            flags[it.work] = done ? 0u : 1u;
+    } else {
         gauss_slide_band<R, CLAMP, 4, RAGGED>(L, wv, alpha_hi);
+    }
 }
 
 template <int R>
-hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
-                    const GaussCoef& coef)
+bool slide_plan(int w, int h, int nframes, StripPlan* sp, BandPlan* plan)
 {
     constexpr int K = 2 * R + 1;
-    const StripPlan sp = make_strip_plan(w);
-    const int nstrips = sp.nstrips, lanes_out = sp.lanes_out;
-    const bool ragged = (w & 3) != 0 ||
-                        (((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0);
-    // 122 VGPRs at k = 5 -> 4 waves/SIMD; 2 at k = 7 and 9.
+    *sp = make_strip_plan(w);
+    // 122 VGPRs at k = 5 -> 4 waves/SIMD; opaque pass 3 waves at k = 7, 2 at k = 9.
     // Band height, measured on 256 x 4K frames on the two kinds of MI355X box met ("slow" boxes
     // copy at 4.4 TB/s instead of 5.5 and prefer short bands by up to 10 %, "fast" ones hardly care):
     //   k = 3: 16 rows (6.23 TB/s fast / 5.50 slow; adaptive tall bands 6.10 / 5.01)
     //   k = 5: 24 rows (6.10 / 5.47; adaptive 6.10 / 5.05) — warm-up rows skip the horizontal pass, so short
     //          bands cost little arithmetic; the general 4-channel pass alone would prefer ~64 rows (-4 % here)
-    //   k >= 7: VALU-bound at 2 waves/SIMD, the 2R warm-up rows hurt: tall adaptive bands + short-band tail
+    //   k >= 7: VALU-bound, the 2R warm-up rows hurt: tall adaptive bands + short-band tail
+    return (K == 3)   ? make_band_plan(h, sp->nstrips, nframes, 5, 16, 16, 16, 0.0, plan)
+           : (K == 5) ? make_band_plan(h, sp->nstrips, nframes, 4, 24, 24, 24, 0.0, plan)
+                      : make_band_plan(h, sp->nstrips, nframes, 3, 96, 270, 40, 0.1, plan);
+}
+
+template <int R>
+hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                    const GaussCoef& coef, uint32_t* d_flags)
+{
+    constexpr int K = 2 * R + 1;
+    constexpr bool kSplit = R >= 3;  // two kernels + flags
+    StripPlan sp;
     BandPlan plan;
-    const bool ok = (K == 3)   ? make_band_plan(h, nstrips, nframes, 5, 16, 16, 16, 0.0, &plan)
-                    : (K == 5) ? make_band_plan(h, nstrips, nframes, 4, 24, 24, 24, 0.0, &plan)
-                               : make_band_plan(h, nstrips, nframes, 2, 96, 270, 40, 0.1, &plan);
-    if (!ok)
+    if (!slide_plan<R>(w, h, nframes, &sp, &plan) || (kSplit && !d_flags))
         return hipErrorInvalidValue;
+    const int nstrips = sp.nstrips, lanes_out = sp.lanes_out;
+    const bool ragged = (w & 3) != 0 ||
+                        (((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0);
     Weights<K> wts;
     for (int j = 0; j < K; j++)
         wts.w[j] = coef.h_w1d[j];
@@ -451,9 +476,18 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
         alpha_hi = (uint32_t)hc << 24;
     }
     const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
-#define MI355_LAUNCH(CL, RG)                                                                                   \
-    hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG>), grid, block, 0, stream, d_in, d_out, w, h, nstrips,     \
-                       lanes_out, plan, wts, alpha_hi)
+#define MI355_LAUNCH1(CL, RG, MD)                                                                               \
+    hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG, MD>), grid, block, 0, stream, d_in, d_out, w, h, nstrips, \
+                       lanes_out, plan, wts, alpha_hi, d_flags)
+#define MI355_LAUNCH(CL, RG)        \
+    do {                            \
+        if constexpr (kSplit) {     \
+            MI355_LAUNCH1(CL, RG, 3); \
+            MI355_LAUNCH1(CL, RG, 4); \
+        } else {                    \
+            MI355_LAUNCH1(CL, RG, 0); \
+        }                           \
+    } while (0)
     if (clamp && ragged)
         MI355_LAUNCH(true, true);
     else if (clamp)
@@ -463,6 +497,7 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     else
         MI355_LAUNCH(false, false);
 #undef MI355_LAUNCH
+#undef MI355_LAUNCH1
     return hipGetLastError();
 }
 
@@ -478,14 +513,27 @@ bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
     return ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 3u) == 0;
 }
 
+size_t gauss_slide_flag_items(int w, int h, int nframes, int k)
+{
+    StripPlan sp;
+    BandPlan plan;
+    bool ok = false;
+    switch (k) {  // only the two-kernel variants (k = 7, 9) use flags
+    case 7: ok = slide_plan<3>(w, h, nframes, &sp, &plan); break;
+    case 9: ok = slide_plan<4>(w, h, nframes, &sp, &plan); break;
+    default: break;
+    }
+    return ok ? (size_t)plan.nwork_a + plan.nwork_b : 0;
+}
+
 hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                              int nframes, const GaussCoef& coef)
+                              int nframes, const GaussCoef& coef, uint32_t* d_flags)
 {
     switch (coef.k) {
-    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef);
-    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef);
-    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef);
-    case 9: return launch_r<4>(stream, d_in, d_out, w, h, nframes, coef);
+    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case 9: return launch_r<4>(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     default: return hipErrorInvalidValue;
     }
 }

@@ -37,7 +37,8 @@ struct WWeights {
 struct WideLane {
     const uint8_t* fin;
     uint8_t* fout;
-    f32x4* vr;  // this wave's LDS row: entry R + p holds pixel p of the strip (p = 0..127), R padding entries per side
+    f32x4* vr;  // this wave's LDS row: entry R + p holds pixel p of the strip (p = 0..127), R padding entries per
+                // side; even entries first, then odd entries (see gauss_wide_band)
     size_t row_bytes;
     uint32_t in_off, out_off;
     int y0, nout, nin, h, lane;
@@ -63,7 +64,11 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
     float acc[K][2 * NCH] = {};
     // horizontal pass: output pixel e of this lane reads strip pixels 2*lane + e - R + t = row entries
     // 2*lane + e + t, t = 0..K-1: one base pointer per lane, immediate offsets per tap
-    const f32x4* win = L.vr + 2 * L.lane;
+    // The row is stored as two planes, even and odd entries (entry e lives in plane e & 1 at index e >> 1), so
+    // that the lanes of one ds_read_b128 touch consecutive 16-byte slots: with the entries of a lane's pixel
+    // pair side by side, lanes l and l + 8 met in the same banks (SQ_LDS_BANK_CONFLICT = half the LDS cycles).
+    constexpr int kPlane = (128 + 2 * R + 2) / 2;
+    const f32x4* win = L.vr + L.lane;  // entry 2*lane + t  ->  plane t & 1, index lane + (t >> 1)
 
     for (int base = 0; base < L.nin; base += K) {
 #pragma unroll
@@ -99,8 +104,10 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
             const int m = i - 2 * R;
             if (m >= 0) {  // wave-uniform: the first 2R rows of a band finish no output row
                 const float* v = acc[(u + 1) % K];
-                L.vr[R + 2 * L.lane] = f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f};
-                L.vr[R + 2 * L.lane + 1] = f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f};
+                // this lane's pixels are entries R + 2*lane and R + 2*lane + 1
+                L.vr[(R & 1) * kPlane + (R >> 1) + L.lane] = f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f};
+                L.vr[((R + 1) & 1) * kPlane + ((R + 1) >> 1) + L.lane] =
+                    f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f};
                 // The other 63 lanes read these entries below.  The hardware executes a wave's LDS operations in
                 // order, but the compiler knows nothing of lanes: without a release/acquire pair at wavefront
                 // scope it may treat the stores as thread-private (it deleted 20 of the 22 in one build of this
@@ -115,7 +122,7 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
                     // entries R and R+1 of the window are this lane's own two pixels: no LDS read for them
                     const f32x4 a = (t == R)       ? f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f}
                                     : (t == R + 1) ? f32x4{v[NCH], v[NCH + 1], v[NCH + 2], NCH == 4 ? v[2 * NCH - 1] : 0.0f}
-                                                   : win[t];
+                                                   : win[(t & 1) * kPlane + (t >> 1)];
 #pragma unroll
                     for (int c = 0; c < NCH; c++) {
                         if (t < K)
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (NCH == 3 && R <= 6) ? 3 : 2) 
 {
     constexpr int K = 2 * R + 1;
     constexpr int H = (R + 1) / 2;  // halo lanes per side (2 px each)
-    __shared__ f32x4 vrow[kWavesPerBlock][128 + 2 * R];
+    __shared__ f32x4 vrow[kWavesPerBlock][128 + 2 * R + 2];  // two planes of (128 + 2R + 2) / 2 entries
     SlideItem it;
     if (!slide_item(plan, nstrips, h, &it))
         return;

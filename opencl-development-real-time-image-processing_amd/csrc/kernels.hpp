@@ -34,8 +34,9 @@ hipError_t launch_gauss_tile(hipStream_t stream, const uint8_t* d_in, uint8_t* d
 
 // register-resident sliding-window kernel (k = 3,5,7,9; width % 4 == 0; 16-byte aligned buffers)
 bool gauss_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+size_t gauss_slide_flag_items(int w, int h, int nframes, int k);
 hipError_t launch_gauss_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
-                              int nframes, const GaussCoef& coef);
+                              int nframes, const GaussCoef& coef, uint32_t* d_flags);
 
 // register-resident kernel for k = 11..17 (2 px per lane, LDS row exchange); width % 2 == 0, 8-byte aligned
 bool gauss_wide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
