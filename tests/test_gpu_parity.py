@@ -110,6 +110,26 @@ def test_gauss_wide_kernel_opaque_fast_path_and_fallback(ctx, pkg, oracle):
             assert np.array_equal(ctx.gauss(img, k, sigma), tiled), (pos, k)
 
 
+@pytest.mark.parametrize("k,sigma", [(5, 1.5), (7, 2.0), (9, 2.5), (11, 3.0), (17, 6.0)])
+def test_gauss_batch_with_opaque_and_non_opaque_frames(ctx, pkg, oracle, k, sigma):
+    """k >= 7 runs the opaque pass and the general pass as two kernels that talk through one flag per work item
+    (frame, band, strip): a batch in which only some frames / bands carry a non-opaque pixel must come out as
+    the tiled kernel computes it, frame by frame."""
+    frames = oracle.synth_rgba(600, 330, 5, first_frame=k, mode=1).copy()   # A = 255
+    frames[1, 17, 33, 3] = 0
+    frames[3, 329, 599, 3] = 254
+    frames[3, 150, 300, 3] = 1
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(frames, k, sigma)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    got = ctx.gauss(frames, k, sigma)
+    assert np.array_equal(got, tiled)
+    # the untouched frames equal what they give alone (no flag leaks across frames)
+    assert np.array_equal(got[0], ctx.gauss(frames[0], k, sigma))
+    assert np.array_equal(got[4], ctx.gauss(frames[4], k, sigma))
+
+
 def test_gauss_wide_kernel_batched_multi_band(ctx, pkg, oracle):
     frames = oracle.synth_rgba(1000, 420, 3, first_frame=1, mode=1)
     ctx.set_impl(pkg.IMPL_TILE)
