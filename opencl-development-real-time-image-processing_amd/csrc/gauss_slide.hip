@@ -207,14 +207,16 @@ struct SlideLane {
 // tested (one ballot over all 64 lanes, halo included) and the pass returns false at the first alpha != 255,
 // before that row has contributed anything: the rows stored so far are correct, and the caller redoes the band
 // with NCH = 4.
-template <int R, bool CLAMP, int NCH, bool RAGGED>
+template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP>
 __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi)
 {
     constexpr int K = 2 * R + 1;
     uint32_t in_off = L.in_off, out_off = L.out_off;
     auto load_row = [&](int i) -> u32x4 {
-        // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed)
-        const int y = clampi(L.y0 - R + min(i, L.nin - 1), 0, L.h - 1);
+        // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed); an UP band
+        // walks from its bottom-most input row to its top-most one
+        const int ii = min(i, L.nin - 1);
+        const int y = clampi(UP ? L.y0 + L.nout - 1 + R - ii : L.y0 - R + ii, 0, L.h - 1);
         const auto rowp = L.fin + (size_t)y * L.row_bytes;  // SGPR pair; + 32-bit lane offset = saddr form
         if constexpr (R <= 2)  // (k = 9: the asm statements keep hipcc from unrolling the trip; k = 7: -4 %)
             lane_offset_here(in_off);
@@ -242,11 +244,17 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
     for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
-    float acc[K][4 * NCH] = {};
+    // k <= 7: ring of the last K input rows, converted to float once (row i lives in slot i % K, static after
+    // unrolling); the vertical sums of an output row are formed when its window is complete — in either walking
+    // direction.  k = 9: K running accumulators instead (input row i is tap j of output row i - j), the form all
+    // sizes used first: same multiply-add chains, same count, but 10 VGPRs fewer here, which is the third wave
+    // per SIMD (168 vs 174); it can only walk down.
+    constexpr bool kRing = R <= 3;
+    static_assert(kRing || !UP, "the accumulator form walks down only");
+    float rows[K][4 * NCH] = {};
 
-    // One trip = K input rows; input row i is tap j of output row m = i - j (m in slot m % K).  The
-    // first 2R rows of a band and the rows of a last partial trip run the same code with their
-    // store masked off: no control flow inside the trip except the store predicate.
+    // One trip = K input rows.  Input row i completes the window of output row m = i - 2R; the first 2R rows of
+    // a band and the rows of a last partial trip only convert (scalar branch below).
     for (int base = 0; base < L.nin; base += K) {
 #pragma unroll
         for (int u = 0; u < K; u++) {
@@ -267,36 +275,54 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                 if (__builtin_amdgcn_ballot_w64((a4 >> 24) != 0xFFu) != 0)  // wave-uniform
                     return false;
             }
-            // vertical pass, pixel by pixel: convert one pixel's channels, fold them into all K
-            // accumulators (input row i is tap j of output row i - j), then move on — few live temporaries
+            if constexpr (kRing) {
 #pragma unroll
-            for (int px = 0; px < 4; px++) {
-                float f[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-                    f[c] = ubyte_f32(p[px], c);
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                    const int s = (u - j + K) % K;
+                for (int px = 0; px < 4; px++)
 #pragma unroll
                     for (int c = 0; c < NCH; c++)
-                        acc[s][px * NCH + c] =
-                            (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], acc[s][px * NCH + c]);
+                        rows[u][px * NCH + c] = ubyte_f32(p[px], c);
+            } else {
+                // rows[] holds accumulators: convert one pixel's channels, fold them into all K of them
+#pragma unroll
+                for (int px = 0; px < 4; px++) {
+                    float f[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; c++)
+                        f[c] = ubyte_f32(p[px], c);
+#pragma unroll
+                    for (int j = 0; j < K; j++) {
+                        const int sl = (u - j + K) % K;
+#pragma unroll
+                        for (int c = 0; c < NCH; c++)
+                            rows[sl][px * NCH + c] =
+                                (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], rows[sl][px * NCH + c]);
+                    }
                 }
             }
-            const int m = i - 2 * R;  // output row that just received its last tap
+            const int m = i - 2 * R;  // output row whose window this input row completes
             // warm-up rows (m < 0) and the rows of a last partial trip (m >= nout) produce no output: skip
             // the horizontal pass and the store with a scalar branch (m and nout live in SGPRs, so EXEC
             // stays full inside, which the DPP reads of the horizontal pass require)
             if (m >= 0 && m < L.nout) {
-                const float* v = acc[(u + 1) % K];
+                // vertical pass in the canonical order, top tap first: a DOWN band holds the window oldest row
+                // = top row (slot u+1 ... slot u), an UP band newest row = top row (slot u, u-1, ...) — a static
+                // permutation of the same multiply-add chain, so both directions give the same bits
+                auto vsum = [&](int e) -> float {
+                    if constexpr (!kRing)
+                        return rows[(u + 1) % K][e];  // the accumulator that just received its last tap
+                    float a = wv[0] * rows[UP ? u : (u + 1) % K][e];
+#pragma unroll
+                    for (int j = 1; j < K; j++)
+                        a = __builtin_fmaf(wv[j], rows[UP ? (u - j + K) % K : (u + 1 + j) % K][e], a);
+                    return a;
+                };
                 u32x4 o;
                 if constexpr (R == 2) {
                     float hres[4][4];  // [channel][pixel]
 #pragma unroll
                     for (int c = 0; c < NCH; c++)
-                        hpass5_dpp(v[0 * NCH + c], v[1 * NCH + c], v[2 * NCH + c], v[3 * NCH + c], wv[0], wv[1], wv[2],
-                                   wv[3], wv[4], hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
+                        hpass5_dpp(vsum(0 * NCH + c), vsum(1 * NCH + c), vsum(2 * NCH + c), vsum(3 * NCH + c), wv[0],
+                                   wv[1], wv[2], wv[3], wv[4], hres[c][0], hres[c][1], hres[c][2], hres[c][3]);
                     if constexpr (CLAMP) {
 #pragma unroll
                         for (int px = 0; px < 4; px++)
@@ -308,6 +334,10 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                         cvt_pack3x4(hres, alpha_hi, o);
                     }
                 } else {
+                    float v[4 * NCH];
+#pragma unroll
+                    for (int e = 0; e < 4 * NCH; e++)
+                        v[e] = vsum(e);
 #pragma unroll
                     for (int px = 0; px < 4; px++) {
                         float r4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -334,7 +364,7 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                     }
                 }
                 if (L.stores) {
-                    const auto rowp = L.fout + (size_t)(L.y0 + m) * L.row_bytes;
+                    const auto rowp = L.fout + (size_t)(UP ? L.y0 + L.nout - 1 - m : L.y0 + m) * L.row_bytes;
                     if constexpr (R <= 2)
                         lane_offset_here(out_off);
                     if constexpr (RAGGED) {
@@ -362,7 +392,7 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
 // instead of 2).  Kernel MODE 3 leaves flags[work] = 0 (band done) or 1; kernel MODE 4 redoes the flagged bands
 // and exits at once everywhere else (gauss_wide.hip does the same).
 template <int R, bool CLAMP, bool RAGGED, int MODE>
-__global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
+__global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1) void gauss_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
     BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi, uint32_t* __restrict__ flags)
 {
@@ -414,15 +444,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_slide_kernel(
     // RT/src/ProgramHandler.cpp:127): with every alpha tap 255 the blurred alpha is one constant byte, which
     // the host computes with the same float chain (std::fmaf) — 25 % of the arithmetic gone, same bits.
     // A band that meets any other alpha value is redone in full.
+    // Odd bands walk UP, so that a band and its lower neighbour read their shared boundary rows (the 2R rows
+    // each needs from the other) at the same moment and the second reader hits L2 (sobel_slide.hip does the
+    // same; measured there: HBM reads -12 %).  Wave-uniform: two instantiations of the band code.
+    const bool up = (it.band & 1) != 0;
+    auto run = [&](auto nch) -> bool {
+        constexpr int NCH = decltype(nch)::value;
+        if constexpr (R <= 3) {  // (the k = 9 form walks down only)
+            if (up)
+                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true>(L, wv, alpha_hi);
+        }
+        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false>(L, wv, alpha_hi);
+    };
     if constexpr (MODE == 0) {
-        if (!gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi))
-            gauss_slide_band<R, CLAMP, 4, RAGGED>(L, wv, alpha_hi);
+        if (!run(std::integral_constant<int, 3>{}))
+            run(std::integral_constant<int, 4>{});
     } else if constexpr (MODE == 3) {
-        const bool done = gauss_slide_band<R, CLAMP, 3, RAGGED>(L, wv, alpha_hi);
+        const bool done = run(std::integral_constant<int, 3>{});
         if (lane == 0)
             flags[it.work] = done ? 0u : 1u;
     } else {
-        gauss_slide_band<R, CLAMP, 4, RAGGED>(L, wv, alpha_hi);
+        run(std::integral_constant<int, 4>{});
     }
 }
 
