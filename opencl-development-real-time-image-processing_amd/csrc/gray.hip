@@ -5,13 +5,16 @@
 // (the reference writes 16 B/px and converts on one host thread).  Gray value = the CPU path's
 // double-precision formula (src/Grayscale/grayscale.cpp:237), bit-exact.
 //
-// Pure streaming: 4 px (16 B) per lane per access, 4 independent accesses in flight per lane,
-// grid-stride over the flat pixel array (frames are tightly packed, so a batch is one array).
+// Pure streaming, 4 px (16 B) per lane per access, 4 independent accesses in flight per lane.  Two shapes:
+// gray_strip_kernel (rows of 4-pixel multiples: a wave walks a 1-KiB-wide strip of a 4-row band, as the
+// sliding-window kernels do) and gray_vec_kernel (anything else: grid-stride over the flat pixel array; frames
+// are tightly packed, so a batch is one array).
 // Algorithmic bytes: 8 B/px (RGBA out) or 5 B/px (1-channel out).  Bound: HBM.
 #include <cstdlib>
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "slide_common.hpp"
 
 namespace mi355 {
 
@@ -72,6 +75,56 @@ __global__ __launch_bounds__(kGrayThreads) void gray_vec_kernel(const u32x4* __r
     }
 }
 
+// Same arithmetic, the access shape of the sliding-window kernels: a wave owns a 1-KiB-wide column strip (64 lanes
+// x 4 px) of a band of rows and walks down it, 4 rows in flight.  Work items are numbered strip-fastest, so what
+// the chip has in flight is one compact window of the batch.
+template <bool ONE_CH>
+__global__ __launch_bounds__(kSlideWavesPerBlock * 64) void gray_strip_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads, int h, int nstrips, BandPlan plan)
+{
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
+        return;
+    const int lane = threadIdx.x & 63;
+    const int q = it.strip * 64 + lane;
+    if (q >= quads)
+        return;
+    const size_t row_in = (size_t)quads * 16, row_out = ONE_CH ? (size_t)quads * 4 : row_in;
+    const auto fin = uniform_ptr(in + it.frame * row_in * h);
+    const auto fout = uniform_ptr(out + it.frame * row_out * h);
+    uint32_t in_off = (uint32_t)q * 16u, out_off = (uint32_t)q * (ONE_CH ? 4u : 16u);
+    constexpr int U = 4;
+    for (int r0 = 0; r0 < it.nout; r0 += U) {
+        u32x4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int y = it.y0 + min(r0 + u, it.nout - 1);
+            lane_offset_here(in_off);
+            p[u] = __builtin_nontemporal_load((global_ptr<const u32x4>)(fin + (size_t)y * row_in + in_off));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (r0 + u < it.nout) {  // wave-uniform
+                float gf[4];
+                luma_quad_fast(p[u], gf);
+                const uint32_t g0 = (uint32_t)gf[0], g1 = (uint32_t)gf[1], g2 = (uint32_t)gf[2], g3 = (uint32_t)gf[3];
+                const auto rowp = fout + (size_t)(it.y0 + r0 + u) * row_out;
+                lane_offset_here(out_off);
+                if constexpr (ONE_CH) {
+                    gstore_nt<uint32_t>(rowp + out_off, pack4(g0, g1, g2, g3));
+                } else {
+                    u32x4 o;
+                    o.x = gray_to_rgba(g0);
+                    o.y = gray_to_rgba(g1);
+                    o.z = gray_to_rgba(g2);
+                    o.w = gray_to_rgba(g3);
+                    gstore_nt<u32x4>(rowp + out_off, o);
+                }
+            }
+        }
+    }
+}
+
 // one pixel per thread: tails and buffers that are not 16-byte aligned
 template <bool ONE_CH>
 __global__ __launch_bounds__(kGrayThreads) void gray_px_kernel(const uint8_t* __restrict__ in,
@@ -115,6 +168,29 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
         const char* e = getenv("MI355_TUNE_GRAY_BLOCKS");  // tuning sweeps only
         return (e && atoi(e) > 0) ? (unsigned)atoi(e) : (1u << 20);
     }();
+    // Rows of 4-pixel multiples take the strip-walk kernel with 4-row bands: measured on 256 x 4K frames, same
+    // box, flat kernel 6.36 TB/s, strips of 4 / 8 / 16 / 32 rows 6.61 / 6.49 / 6.39 / 6.27 (1-channel output: 6.08
+    // flat, 6.33 with 4 rows).  MI355_TUNE_GRAY_STRIP (tuning sweeps only): band height, 0 = flat kernel.
+    static const int kStripRows = [] {
+        const char* e = getenv("MI355_TUNE_GRAY_STRIP");
+        return e ? atoi(e) : 4;
+    }();
+    // ... and only where it pays: big batches (8 x 4K frames: -2.5 %, 256: +2 %) of rows that fill the 64-lane
+    // strips (64-pixel-wide frames would leave 48 lanes idle: -23 %)
+    const int strip_quads = w / 4, strip_n = (strip_quads + 63) / 64;
+    const bool strip_ok = (w & 3) == 0 && strip_quads * 100 >= strip_n * 64 * 93 && npx >= ((size_t)1 << 28);
+    if (nquads && kStripRows > 0 && strip_ok) {
+        const int quads = strip_quads, nstrips = strip_n;
+        BandPlan plan;
+        if (!make_band_plan(h, nstrips, nframes, 8, kStripRows, kStripRows, kStripRows, 0.0, &plan))
+            return hipErrorInvalidValue;
+        const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kSlideWavesPerBlock * 64);
+        if (one_channel)
+            hipLaunchKernelGGL(gray_strip_kernel<true>, grid, block, 0, stream, d_in, d_out, quads, h, nstrips, plan);
+        else
+            hipLaunchKernelGGL(gray_strip_kernel<false>, grid, block, 0, stream, d_in, d_out, quads, h, nstrips, plan);
+        return hipGetLastError();
+    }
     if (nquads) {
         const unsigned grid = grid_for(nquads, kGrayThreads * kGrayIlp, kCap);
         if (one_channel)

@@ -581,3 +581,34 @@ def test_results_do_not_depend_on_the_band_plan():
         assert out.returncode == 0, out.stderr[-2000:]
         digests[tuple(sorted(plan.items()))] = out.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_gray_strip_kernel_on_a_big_batch(ctx, pkg, oracle):
+    """Batches of >= 2^28 pixels of 4-pixel-multiple rows take gray.hip's strip-walk kernel, smaller ones the flat
+    kernel: the same 36 x 4K frames as one call and as 9 calls of 4 frames must give the same bytes (checksums
+    add up over the word index), and the first and last frame must equal the oracle."""
+    w, h, n = 3840, 2160, 36
+    per = w * h
+    d_in = ctx.alloc(per * n * 4)
+    ctx.synth_dev(d_in, w, h, n, first_frame=0, seed=0x5EED, mode=0)
+    for filt, bpp in ((pkg.FILTER_GRAY, 4), (pkg.FILTER_GRAY1, 1)):
+        d_out = ctx.alloc(per * n * bpp)
+        ctx.filter_dev(filt, d_in, d_out, w, h, n)
+        whole = ctx.checksum_dev(d_out, per * n * bpp)
+        got_first = np.empty((h, w, bpp), np.uint8)
+        got_last = np.empty((h, w, bpp), np.uint8)
+        ctx.d2h(got_first, d_out)
+        ctx.d2h(got_last, d_out + (n - 1) * per * bpp)
+        d_part = ctx.alloc(per * 4 * bpp)
+        parts = 0
+        for f in range(0, n, 4):
+            ctx.filter_dev(filt, d_in + f * per * 4, d_part, w, h, 4)
+            parts += ctx.checksum_dev(d_part, per * 4 * bpp, index_base=f * per * bpp // 4)
+        assert parts % (1 << 64) == whole
+        for f, got in ((0, got_first), (n - 1, got_last)):
+            frame = oracle.synth_rgba(w, h, 1, first_frame=f, seed=0x5EED, mode=0)[0]
+            ref = oracle.gray_rgba(frame) if bpp == 4 else oracle.gray_rgba_1ch(frame)[..., None]
+            assert np.array_equal(got, ref.reshape(h, w, bpp))
+        ctx.free(d_part)
+        ctx.free(d_out)
+    ctx.free(d_in)
