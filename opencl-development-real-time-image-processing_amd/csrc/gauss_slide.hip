@@ -476,11 +476,12 @@ bool slide_plan(int w, int h, int nframes, StripPlan* sp, BandPlan* plan)
     // 122 VGPRs at k = 5 -> 4 waves/SIMD; opaque pass 3 waves at k = 7, 2 at k = 9.
     // Band height, measured on 256 x 4K frames on the two kinds of MI355X box met ("slow" boxes
     // copy at 4.4 TB/s instead of 5.5 and prefer short bands by up to 10 %, "fast" ones hardly care):
-    //   k = 3: 16 rows (6.23 TB/s fast / 5.50 slow; adaptive tall bands 6.10 / 5.01)
+    //   k = 3: 12 rows (with up/down walking, slow box: 12 rows 5.72 TB/s, 16 rows 5.58, 8 rows 5.69; before it
+    //          16 rows 6.23 fast / 5.50 slow against 6.10 / 5.01 for adaptive tall bands)
     //   k = 5: 24 rows (6.10 / 5.47; adaptive 6.10 / 5.05) — warm-up rows skip the horizontal pass, so short
     //          bands cost little arithmetic; the general 4-channel pass alone would prefer ~64 rows (-4 % here)
     //   k >= 7: VALU-bound, the 2R warm-up rows hurt: tall adaptive bands + short-band tail
-    return (K == 3)   ? make_band_plan(h, sp->nstrips, nframes, 5, 16, 16, 16, 0.0, plan)
+    return (K == 3)   ? make_band_plan(h, sp->nstrips, nframes, 5, 12, 12, 12, 0.0, plan)
            : (K == 5) ? make_band_plan(h, sp->nstrips, nframes, 4, 24, 24, 24, 0.0, plan)
                       : make_band_plan(h, sp->nstrips, nframes, 3, 96, 270, 40, 0.1, plan);
 }
