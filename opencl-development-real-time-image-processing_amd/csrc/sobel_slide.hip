@@ -60,7 +60,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const size_t frame = it.frame;
 
     const int q_lane = strip * lanes_out + lane - 1;
-    const int q_load = clampi(q_lane, 0, quads - 1);
+    // lanes right of the strip's right halo lane are never read by a storing lane: they re-load the halo quad
+    // (same address = same cache line) instead of the next strip's data
+    const int q_load = clampi(q_lane, 0, min(quads - 1, (strip + 1) * lanes_out));
     const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
     const bool edge_strip = (strip == 0) || (4 * (strip * lanes_out + 63) > w);  // wave-uniform
     const int q_end = min((strip + 1) * lanes_out, quads);
@@ -182,7 +184,9 @@ bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
 
 hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes)
 {
-    const StripPlan sp = make_strip_plan(w);
+    // big batches: 48-lane strips (192-byte store spans, see slide_common.hpp: +5 % on 256 x 4K frames); small
+    // ones keep the fewest, widest strips (8 x 4K frames: 48 lanes would cost 8 %)
+    const StripPlan sp = make_strip_plan(w, (size_t)w * h * nframes >= ((size_t)1 << 28) ? 48 : 0);
     // 50 VGPRs -> 8 waves/SIMD, and only 2 warm-up rows per band (loads that hit L2): this light kernel
     // wants many short work items — measured at steady clocks on 256 x 4K frames: 16-row bands 5.2 TB/s,
     // 32 rows 5.0, 64 rows 4.5, 128 rows 4.2
