@@ -66,3 +66,42 @@ def test_no_product_file_references_the_oracle():
                     if needle in text:
                         bad.append((f, needle))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_links_from_c(pkg, tmp_path):
+    """The drop-in boundary is a C ABI: include/mi355_imgfilter.h must compile as C99 (what a cgo / JNI / ctypes-free
+    C host includes) and a C program must link against the library and get sane answers from the entry points that
+    need no GPU."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.dirname(pkg.imgfilter.library_path())
+    src = tmp_path / "c_host.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "mi355_imgfilter.h"
+int main(void) {
+    float w[25];
+    mi355_ctx* ctx = (mi355_ctx*)0;
+    int n = -1;
+    if (mi355_gauss_weights(5, 1.5f, w) != MI355_OK) return 1;
+    if (mi355_gauss_weights(4, 1.5f, w) != MI355_ERR_BAD_ARG) return 2;
+    if (mi355_filter_out_bpp(MI355_FILTER_SOBEL) != 1 || mi355_filter_out_bpp(MI355_FILTER_GAUSS) != 4) return 3;
+    if (mi355_device_count(&n) != MI355_OK || n < 0) return 4;
+    if (n == 0 && mi355_ctx_create(0, &ctx) != MI355_ERR_NO_DEVICE) return 5;
+    if (ctx) mi355_ctx_destroy(ctx);
+    if (!mi355_strerror(MI355_ERR_BAD_ARG) || !strlen(mi355_build_info())) return 6;
+    printf("%.9g %s\n", (double)w[12], mi355_build_info());
+    return 0;
+}
+''')
+    exe = tmp_path / "c_host"
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src),
+           "-L", lib_dir, "-lmi355_imgfilter", "-Wl,-rpath," + lib_dir, "-o", str(exe)]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    centre = float(run.stdout.split()[0])
+    assert abs(centre - float(pkg.gauss_weights(5, 1.5)[2, 2])) < 1e-9
