@@ -173,6 +173,116 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     }
 }
 
+
+// lane l <- lane l-1 / l+1, and the lane that has no such neighbour (0 / 63) takes `edge` instead (a DPP move
+// without bound_ctrl leaves the destination, pre-loaded with `edge`, untouched there)
+__device__ __forceinline__ float dpp_left_or(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float dpp_right_or(float v, float edge)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge),
+                                                                 __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
+}
+
+// The aligned shape (width % 4 == 0, 16-byte-aligned input, 4-byte-aligned output): a wave owns exactly 64 pixel
+// quads — all 64 lanes produce output, the row accesses are whole aligned 1-KiB loads and 256-byte stores like
+// gray.hip's strip kernel — and the one pixel it needs on either side of its strip is fetched separately: a
+// wave-uniform address (reflect-101 applied to it at the image border, so the arithmetic has no border cases),
+// i.e. a scalar load.  sobel_slide_kernel above spends a halo LANE per side (62 output lanes, every access shifted
+// by 16 bytes, 240-byte store spans) and remains the kernel for everything else.
+__global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
+    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int quads, int h, int nstrips, BandPlan plan)
+{
+    constexpr int K = 3;
+    const int lane = threadIdx.x & 63;
+    SlideItem it;
+    if (!slide_item(plan, nstrips, h, &it))
+        return;
+    const int w = 4 * quads, y0 = it.y0, nout = it.nout, nin = nout + 2;
+    const int q = it.strip * 64 + lane;
+    const int q_last = min((it.strip + 1) * 64, quads) - 1;  // last quad of this strip (wave-uniform)
+    const bool active = q <= q_last;
+    const bool partial = q_last - it.strip * 64 < 63;  // wave-uniform: only the last strip of a row can be partial
+    const int x_left = reflect101(4 * it.strip * 64 - 1, w);   // x = -1 -> 1
+    const int x_right = reflect101(4 * (q_last + 1), w);        // x = w  -> w-2
+
+    const size_t row_bytes = (size_t)w * 4;
+    const auto fin = uniform_ptr(in + it.frame * row_bytes * h);
+    const auto fout = uniform_ptr(out + it.frame * (size_t)w * h);
+    uint32_t in_off = (uint32_t)min(q, q_last) * 16u;
+    uint32_t out_off = (uint32_t)min(q, q_last) * 4u;
+    const bool up = (it.band & 1) != 0;  // see sobel_slide_kernel
+
+    struct Row {
+        u32x4 p;
+        uint32_t hl, hr;
+    };
+    auto load_row = [&](int i) -> Row {
+        const int ii = min(i, nin - 1);
+        const int y = reflect101(up ? y0 + nout - ii : y0 - 1 + ii, h);
+        const auto rowp = fin + (size_t)y * row_bytes;
+        lane_offset_here(in_off);
+        Row r;
+        r.p = gload<u32x4>(rowp + in_off);
+        r.hl = gload<uint32_t>(rowp + (uint32_t)x_left * 4u);   // uniform addresses
+        r.hr = gload<uint32_t>(rowp + (uint32_t)x_right * 4u);
+        return r;
+    };
+
+    constexpr int PF = 3;
+    Row qr[K];
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        qr[u] = load_row(u);
+
+    float L[K][4] = {};
+    float HL[K] = {}, HR[K] = {};  // luminance of the two halo pixels, same ring
+
+    for (int base = 0; base < nin; base += K) {
+#pragma unroll
+        for (int u = 0; u < K; u++) {
+            const int i = base + u;
+            const Row r = qr[u];
+            qr[(u + PF) % K] = load_row(i + PF);
+            luma_quad_fast(r.p, L[u]);
+            HL[u] = luma_px_fast(r.hl);
+            HR[u] = luma_px_fast(r.hr);
+
+            const int st = (u + 1) % K, sm = (u + 2) % K, sb = u;  // oldest, middle, newest row
+            float cs[4], cd[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                cs[j] = __builtin_fmaf(2.0f, L[sm][j], L[st][j]) + L[sb][j];
+                cd[j] = L[sb][j] - L[st][j];
+            }
+            const float csL = __builtin_fmaf(2.0f, HL[sm], HL[st]) + HL[sb], cdL = HL[sb] - HL[st];
+            const float csR = __builtin_fmaf(2.0f, HR[sm], HR[st]) + HR[sb], cdR = HR[sb] - HR[st];
+            const float csl = dpp_left_or(cs[3], csL), cdl = dpp_left_or(cd[3], cdL);
+            float csr = dpp_right_or(cs[0], csR), cdr = dpp_right_or(cd[0], cdR);
+            if (partial) {  // the strip ends inside the wave: its last lane takes the halo column too
+                if (q == q_last) {
+                    csr = csR;
+                    cdr = cdR;
+                }
+            }
+            const float gxs[4] = {cs[1] - csl, cs[2] - cs[0], cs[3] - cs[1], csr - cs[2]};
+            const float gys[4] = {__builtin_fmaf(2.0f, cd[0], cdl) + cd[1], __builtin_fmaf(2.0f, cd[1], cd[0]) + cd[2],
+                                  __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3], __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr};
+            const uint32_t res = sobel_mag_quad(gxs, gys);
+            const int m = i - 2;
+            if (active && m >= 0 && m < nout) {
+                const auto rowp = fout + (size_t)(up ? y0 + nout - 1 - m : y0 + m) * w;
+                lane_offset_here(out_off);
+                gstore_nt<uint32_t>(rowp + out_off, res);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h)
@@ -184,9 +294,28 @@ bool sobel_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int
 
 hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes)
 {
+    static const int kStripMode = [] {
+        // tuning sweeps and tests only: 0 = never use the aligned-strip kernel, 2 = whenever the rows allow it
+        const char* e = getenv("MI355_TUNE_SOBEL_STRIP");
+        return e ? atoi(e) : 1;
+    }();
+    const bool kStripOff = kStripMode == 0;
+    // big batches of aligned rows: the aligned-strip kernel (256 x 4K frames, same box: 5.81-5.99 TB/s against
+    // 5.67-5.72 for the halo-lane kernel; 640x512 x 8000: 5.48 / 5.24; but 8 x 4K frames: 5.45 / 5.86)
+    const bool big = (size_t)w * h * nframes >= ((size_t)1 << 28) || kStripMode == 2;
+    if (!kStripOff && big && (w & 3) == 0 && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
+        const int quads = w / 4, nstrips = (quads + 63) / 64;
+        BandPlan plan;
+        if (!make_band_plan(h, nstrips, nframes, 8, 16, 16, 16, 0.0, &plan))
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(sobel_strip_kernel, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
+                           stream, d_in, d_out, quads, h, nstrips, plan);
+        return hipGetLastError();
+    }
     // big batches: 48-lane strips (192-byte store spans, see slide_common.hpp: +5 % on 256 x 4K frames); small
     // ones keep the fewest, widest strips (8 x 4K frames: 48 lanes would cost 8 %)
-    const StripPlan sp = make_strip_plan(w, (size_t)w * h * nframes >= ((size_t)1 << 28) ? 48 : 0);
+    const StripPlan sp = make_strip_plan(w, big ? 48 : 0);
     // 50 VGPRs -> 8 waves/SIMD, and only 2 warm-up rows per band (loads that hit L2): this light kernel
     // wants many short work items — measured at steady clocks on 256 x 4K frames: 16-row bands 5.2 TB/s,
     // 32 rows 5.0, 64 rows 4.5, 128 rows 4.2

@@ -551,7 +551,7 @@ pkg = e.load_package()
 rng = np.random.default_rng(99)
 h = hashlib.sha256()
 with pkg.Context(0) as ctx:
-    for (n, hh, ww) in [(3, 131, 500), (2, 97, 1023), (1, 300, 252)]:
+    for (n, hh, ww) in [(3, 131, 500), (2, 97, 1023), (1, 300, 252), (2, 70, 4), (1, 33, 260), (2, 40, 1024)]:
         x = rng.integers(0, 256, (n, hh, ww, 4), dtype=np.uint8)
         y = x.copy(); y[..., 3] = 255
         for img in (x, y):
@@ -560,6 +560,7 @@ with pkg.Context(0) as ctx:
             for k, s in [(3, 0.8), (5, 1.5), (7, 2.0)]:
                 h.update(ctx.pipeline(img, k, s).tobytes())
             h.update(ctx.sobel(img).tobytes())
+            h.update(ctx.gray1(img).tobytes())
 print(h.hexdigest())
 """
 
@@ -574,7 +575,10 @@ def test_results_do_not_depend_on_the_band_plan():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for plan in ({}, {"MI355_TUNE_BAND_ROWS": "1"}, {"MI355_TUNE_BAND_ROWS": "7"},
-                 {"MI355_TUNE_BAND_ROWS": "50", "MI355_TUNE_TAIL_ROWS": "3", "MI355_TUNE_TAIL_FRAC": "0.3"}):
+                 {"MI355_TUNE_BAND_ROWS": "50", "MI355_TUNE_TAIL_ROWS": "3", "MI355_TUNE_TAIL_FRAC": "0.3"},
+                 # kernels that normally serve big batches only: Sobel aligned strips, gray strips
+                 {"MI355_TUNE_SOBEL_STRIP": "2", "MI355_TUNE_BAND_ROWS": "5"}, {"MI355_TUNE_SOBEL_STRIP": "2"},
+                 {"MI355_TUNE_SOBEL_STRIP": "0", "MI355_TUNE_LANES_OUT": "48"}):
         env = dict(os.environ, **plan)
         out = subprocess.run([sys.executable, "-c", _BAND_PLAN_SCRIPT, root], env=env, capture_output=True,
                              text=True, timeout=300)
@@ -583,15 +587,16 @@ def test_results_do_not_depend_on_the_band_plan():
     assert len(set(digests.values())) == 1, digests
 
 
-def test_gray_strip_kernel_on_a_big_batch(ctx, pkg, oracle):
-    """Batches of >= 2^28 pixels of 4-pixel-multiple rows take gray.hip's strip-walk kernel, smaller ones the flat
-    kernel: the same 36 x 4K frames as one call and as 9 calls of 4 frames must give the same bytes (checksums
-    add up over the word index), and the first and last frame must equal the oracle."""
+def test_big_batch_kernels(ctx, pkg, oracle):
+    """Batches of >= 2^28 pixels of 4-pixel-multiple rows take gray.hip's strip-walk kernel and sobel_slide.hip's
+    aligned-strip kernel, smaller ones the flat / halo-lane kernels: the same 36 x 4K frames as one call and as 9
+    calls of 4 frames must give the same bytes (checksums add up over the word index), and the first and last
+    frame must equal the oracle."""
     w, h, n = 3840, 2160, 36
     per = w * h
     d_in = ctx.alloc(per * n * 4)
     ctx.synth_dev(d_in, w, h, n, first_frame=0, seed=0x5EED, mode=0)
-    for filt, bpp in ((pkg.FILTER_GRAY, 4), (pkg.FILTER_GRAY1, 1)):
+    for filt, bpp in ((pkg.FILTER_GRAY, 4), (pkg.FILTER_GRAY1, 1), (pkg.FILTER_SOBEL, 1)):
         d_out = ctx.alloc(per * n * bpp)
         ctx.filter_dev(filt, d_in, d_out, w, h, n)
         whole = ctx.checksum_dev(d_out, per * n * bpp)
@@ -607,7 +612,8 @@ def test_gray_strip_kernel_on_a_big_batch(ctx, pkg, oracle):
         assert parts % (1 << 64) == whole
         for f, got in ((0, got_first), (n - 1, got_last)):
             frame = oracle.synth_rgba(w, h, 1, first_frame=f, seed=0x5EED, mode=0)[0]
-            ref = oracle.gray_rgba(frame) if bpp == 4 else oracle.gray_rgba_1ch(frame)[..., None]
+            ref = (oracle.sobel_rgba(frame) if filt == pkg.FILTER_SOBEL
+                   else oracle.gray_rgba(frame) if bpp == 4 else oracle.gray_rgba_1ch(frame))
             assert np.array_equal(got, ref.reshape(h, w, bpp))
         ctx.free(d_part)
         ctx.free(d_out)
