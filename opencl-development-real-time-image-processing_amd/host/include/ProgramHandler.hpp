@@ -1,6 +1,7 @@
-// ProgramHandler.hpp — same public surface as the reference's include/ProgramHandler.hpp:6-45: flag
-// holder, InitOpenCL (device pick + method -> kernel name + kernel-file pick), and the two PerformOpenCL
-// overloads that dispatch to Controller by method string ("GRAYSCALE" | "EDGE" | "GAUSSIAN").
+// ProgramHandler.hpp — the class the reference application drives (include/ProgramHandler.hpp:6-45 there), with
+// the same public members so that RealtimeImageProcessing.cpp compiles against it unchanged: it holds the run
+// flags, picks the device, and turns a method string ("GRAYSCALE" | "EDGE" | "GAUSSIAN") into the matching
+// Controller::PerformCL* call.  Private state is this build's own.
 #ifndef PROGRAMHANDLER_H
 #define PROGRAMHANDLER_H
 
@@ -20,16 +21,27 @@
 class ProgramHandler
 {
 public:
+    // Flags as the application passes them (RT/RealtimeImageProcessing.cpp:435 in the reference); the Gaussian
+    // defaults are the reference's (k = 17, sigma = 6).
     ProgramHandler(int number_of_iterations, bool log_events, bool display_images, bool display_terminal_results,
                    bool bypass_image_support, int gaussian_kernel_size = 17, float gaussian_sigma = 6.0f);
 
+    // --- set-up -------------------------------------------------------------------------------------------
+    void SetDeviceProperties(int platform_index, int device_index);
+    // kernel_index is the filter family ("GRAYSCALE" | "EDGE" | "GAUSSIAN"); `kernels` = {image, buffer} source
+    // file names, kept as labels only — this build has no kernel sources to compile.
+    void AddKernels(std::vector<std::string> kernels, std::string kernel_index);
     void InitLogger(Logger& logger, Logger::LogLevel level, bool save_to_file);
+    // Platform / device pick, context, queue, "program" and "kernel" handles for `method`.
     void InitOpenCL(Controller& controller, cl_context* context, cl_command_queue* command_queue,
                     cl_program* program, cl_kernel* kernel, std::string method, Logger& logger);
 
-    void AddKernels(std::vector<std::string> kernels, std::string kernel_index);
-    void SetDeviceProperties(int platform_index, int device_index);
-
+    // --- the hot path -------------------------------------------------------------------------------------
+    // One frame already in memory (the real-time loop).  Returns the filter output as the reference does.
+    std::vector<unsigned char> PerformOpenCL(Controller& controller, const cv::Mat& input_frame, cl_context* context,
+                                             cl_command_queue* command_queue, cl_kernel* kernel, cl_int& width,
+                                             cl_int& height, Logger& logger, std::string method);
+    // An image file, NUMBER_OF_ITERATIONS times, with the averaged profiling figures (the benchmark loop).
     std::vector<unsigned char> PerformOpenCL(Controller& controller, std::string image_path, cl_context* context,
                                              cl_command_queue* command_queue, cl_kernel* kernel,
                                              double& avg_opencl_execution_time, double& avg_opencl_kernel_write_time,
@@ -37,28 +49,21 @@ public:
                                              double& avg_opencl_kernel_read_time, double& avg_opencl_kernel_operation,
                                              cl_int& width, cl_int& height, Logger& logger, std::string method);
 
-    std::vector<unsigned char> PerformOpenCL(Controller& controller, const cv::Mat& input_frame, cl_context* context,
-                                             cl_command_queue* command_queue, cl_kernel* kernel, cl_int& width,
-                                             cl_int& height, Logger& logger, std::string method);
-
 private:
-    bool LOG_EVENTS;
-    bool DISPLAY_IMAGES;
-    bool DISPLAY_TERMINAL_RESULTS;
-    bool BYPASS_IMAGE_SUPPORT;
+    struct Options {
+        int iterations = 1;
+        bool log_events = false, display_images = false, display_terminal_results = false;
+        bool bypass_image_support = true;
+        int platform_index = 0, device_index = 0;
+        int gauss_k = 17;
+        float gauss_sigma = 6.0f;
+    };
+    Options m_opt;
+    std::vector<std::string> m_methods;                              // the three family names, in the reference's order
+    std::map<std::string, std::vector<std::string>> m_kernel_files;  // family -> {image kernel, buffer kernel}
 
-    int NUMBER_OF_ITERATIONS;
-    int PLATFORM_INDEX;
-    int DEVICE_INDEX;
-
-    int GAUSSIAN_KERNEL_SIZE;
-    float GAUSSIAN_SIGMA;
-
-    std::vector<std::string> METHOD;
-    std::map<std::string, std::vector<std::string>> KERNELS;
-
-    void GetImageOpenCL(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width,
-                        cl_int* height, Logger& logger);
+    void LoadFrame(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width, cl_int* height,
+                   Logger& logger);
 };
 
 #endif  // PROGRAMHANDLER_H

@@ -14,8 +14,8 @@ static std::string query(cl_platform_id id, cl_platform_info name)
 }
 
 InfoPlatform::InfoPlatform(cl_platform_id id)
-    : m_profile(query(id, CL_PLATFORM_PROFILE)), m_name(query(id, CL_PLATFORM_NAME)),
-      m_version(query(id, CL_PLATFORM_VERSION)), m_vendor(query(id, CL_PLATFORM_VENDOR))
+    : m_info.profile(query(id, CL_PLATFORM_PROFILE)), m_info.name(query(id, CL_PLATFORM_NAME)),
+      m_info.version(query(id, CL_PLATFORM_VERSION)), m_info.vendor(query(id, CL_PLATFORM_VENDOR))
 {
 }
 
@@ -27,19 +27,19 @@ void InfoPlatform::DisplaySinglePlatformInfo(cl_platform_id id, cl_platform_info
 void InfoPlatform::Display()
 {
     std::cout << "\nPLATFORM PROPERTIES:" << std::endl;
-    std::cout << "\tCL_PLATFORM_PROFILE\t" << m_profile << std::endl;
-    std::cout << "\tCL_PLATFORM_NAME\t" << m_name << std::endl;
-    std::cout << "\tCL_PLATFORM_VERSION\t" << m_version << std::endl;
-    std::cout << "\tCL_PLATFORM_VENDOR\t" << m_vendor << std::endl;
+    std::cout << "\tCL_PLATFORM_PROFILE\t" << m_info.profile << std::endl;
+    std::cout << "\tCL_PLATFORM_NAME\t" << m_info.name << std::endl;
+    std::cout << "\tCL_PLATFORM_VERSION\t" << m_info.version << std::endl;
+    std::cout << "\tCL_PLATFORM_VENDOR\t" << m_info.vendor << std::endl;
 }
 
 std::string InfoPlatform::GetPlatformInfo(cl_platform_info name)
 {
     switch (name) {
-    case CL_PLATFORM_PROFILE: return m_profile;
-    case CL_PLATFORM_NAME: return m_name;
-    case CL_PLATFORM_VERSION: return m_version;
-    case CL_PLATFORM_VENDOR: return m_vendor;
+    case CL_PLATFORM_PROFILE: return m_info.profile;
+    case CL_PLATFORM_NAME: return m_info.name;
+    case CL_PLATFORM_VERSION: return m_info.version;
+    case CL_PLATFORM_VENDOR: return m_info.vendor;
     default: std::cerr << "Unrecognised platform info" << std::endl; return {};
     }
 }

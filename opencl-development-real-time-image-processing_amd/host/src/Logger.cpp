@@ -6,6 +6,20 @@
 #include <ctime>
 #include <stdexcept>
 
+namespace {
+
+const char* level_name(Logger::LogLevel level)
+{
+    switch (level) {
+    case Logger::LogLevel::INFO: return "INFO";
+    case Logger::LogLevel::WARNING: return "WARNING";
+    case Logger::LogLevel::ERROR: return "ERROR";
+    }
+    return "UNKNOWN";
+}
+
+}  // namespace
+
 Logger& Logger::getInstance()
 {
     static Logger instance;
@@ -16,8 +30,8 @@ Logger::Logger() = default;
 
 Logger::~Logger()
 {
-    if (m_log_file.is_open())
-        m_log_file.close();
+    if (m_sinks.file.is_open())
+        m_sinks.file.close();
 }
 
 std::string Logger::getCurrentTime()
@@ -31,39 +45,30 @@ std::string Logger::getCurrentTime()
     return oss.str();
 }
 
-std::string Logger::_printLogLevel(LogLevel level)
-{
-    switch (level) {
-    case LogLevel::INFO: return "INFO";
-    case LogLevel::WARNING: return "WARNING";
-    case LogLevel::ERROR: return "ERROR";
-    }
-    return "UNKNOWN";
-}
 
 void Logger::setLogFile(const std::string& file_name, bool save_to_file)
 {
-    std::lock_guard<std::mutex> lock(m_mutex);
-    m_save_to_file = save_to_file;
-    if (m_log_file.is_open())
-        m_log_file.close();
-    m_log_file.open(file_name, std::ios::out | std::ios::app);
-    if (!m_log_file)
+    std::lock_guard<std::mutex> lock(m_guard);
+    m_sinks.to_file = save_to_file;
+    if (m_sinks.file.is_open())
+        m_sinks.file.close();
+    m_sinks.file.open(file_name, std::ios::out | std::ios::app);
+    if (!m_sinks.file)
         throw std::runtime_error("Failed to open log file: " + file_name);
 }
 
-void Logger::setTerminalDisplay(bool print_on_terminal) { m_print_terminal = print_on_terminal; }
+void Logger::setTerminalDisplay(bool print_on_terminal) { m_sinks.to_terminal = print_on_terminal; }
 
-void Logger::setLogLevel(LogLevel level) { m_set_level = level; }
+void Logger::setLogLevel(LogLevel level) { m_sinks.terminal_level = level; }
 
 void Logger::log(const std::string& message, LogLevel level)
 {
-    std::lock_guard<std::mutex> lock(m_mutex);
-    const std::string line = "[" + getCurrentTime() + "][" + _printLogLevel(level) + "] " + message;
-    if (m_set_level == level && m_print_terminal)
+    std::lock_guard<std::mutex> lock(m_guard);
+    const std::string line = "[" + getCurrentTime() + "][" + level_name(level) + "] " + message;
+    if (m_sinks.terminal_level == level && m_sinks.to_terminal)
         std::cout << line << std::endl;
-    if (m_save_to_file && m_log_file.is_open())
-        m_log_file << line << std::endl;
+    if (m_sinks.to_file && m_sinks.file.is_open())
+        m_sinks.file << line << std::endl;
 }
 
 void Logger::PrintEndToEndExecutionTime(std::string method, double total_execution_time_ms)
@@ -98,14 +103,14 @@ void Logger::PrintSummary(double& opencl_kernel_execution_time, double& opencl_k
                           double& opencl_kernel_read_time, double& opencl_execution_time,
                           double& opencl_kernel_operation_time, double& cpu_execution_time)
 {
-    if (m_print_terminal)
+    if (m_sinks.to_terminal)
         std::cout << "\n **************************************** START OF OpenCL SUMMARY "
                      "**************************************** "
                   << std::endl;
     PrintEndToEndExecutionTime("OpenCL", opencl_execution_time);
     PrintRawKernelExecutionTime(opencl_kernel_execution_time, opencl_kernel_write_time, opencl_kernel_read_time,
                                 opencl_kernel_operation_time);
-    if (m_print_terminal) {
+    if (m_sinks.to_terminal) {
         std::cout << " **************************************** END OF OpenCL SUMMARY "
                      "**************************************** "
                   << std::endl;
@@ -114,7 +119,7 @@ void Logger::PrintSummary(double& opencl_kernel_execution_time, double& opencl_k
                   << std::endl;
     }
     PrintEndToEndExecutionTime("CPU", cpu_execution_time);
-    if (m_print_terminal)
+    if (m_sinks.to_terminal)
         std::cout << "\n **************************************** END OF CPU SUMMARY "
                      "**************************************** "
                   << std::endl;

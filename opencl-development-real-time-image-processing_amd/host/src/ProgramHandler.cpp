@@ -15,11 +15,15 @@
 ProgramHandler::ProgramHandler(int number_of_iterations, bool log_events, bool display_images,
                                bool display_terminal_results, bool bypass_image_support, int gaussian_kernel_size,
                                float gaussian_sigma)
-    : LOG_EVENTS{log_events}, DISPLAY_IMAGES{display_images}, DISPLAY_TERMINAL_RESULTS{display_terminal_results},
-      BYPASS_IMAGE_SUPPORT{bypass_image_support}, NUMBER_OF_ITERATIONS{number_of_iterations}, PLATFORM_INDEX{0},
-      DEVICE_INDEX{0}, GAUSSIAN_KERNEL_SIZE{gaussian_kernel_size}, GAUSSIAN_SIGMA{gaussian_sigma}
 {
-    METHOD = {"GRAYSCALE", "GAUSSIAN"};
+    m_opt.iterations = number_of_iterations;
+    m_opt.log_events = log_events;
+    m_opt.display_images = display_images;
+    m_opt.display_terminal_results = display_terminal_results;
+    m_opt.bypass_image_support = bypass_image_support;
+    m_opt.gauss_k = gaussian_kernel_size;
+    m_opt.gauss_sigma = gaussian_sigma;
+    m_methods = {"GRAYSCALE", "GAUSSIAN"};
 }
 
 void ProgramHandler::InitLogger(Logger& logger, Logger::LogLevel level, bool save_to_file)
@@ -27,7 +31,7 @@ void ProgramHandler::InitLogger(Logger& logger, Logger::LogLevel level, bool sav
     try {
         logger.setLogFile("RealtimeImageProcessing.log", save_to_file);
         logger.setLogLevel(level);
-        logger.setTerminalDisplay(DISPLAY_TERMINAL_RESULTS);
+        logger.setTerminalDisplay(m_opt.display_terminal_results);
         logger.log("Initialised logger", Logger::LogLevel::INFO);
     } catch (const std::exception& e) {
         std::cerr << "Error setting log file: " << e.what() << std::endl;
@@ -36,36 +40,36 @@ void ProgramHandler::InitLogger(Logger& logger, Logger::LogLevel level, bool sav
 
 void ProgramHandler::AddKernels(std::vector<std::string> kernels, std::string kernel_index)
 {
-    KERNELS.insert({kernel_index, kernels});
+    m_kernel_files.insert({kernel_index, kernels});
 }
 
 void ProgramHandler::SetDeviceProperties(int platform_index, int device_index)
 {
-    PLATFORM_INDEX = platform_index;
-    DEVICE_INDEX = device_index;
+    m_opt.platform_index = platform_index;
+    m_opt.device_index = device_index;
 }
 
 void ProgramHandler::InitOpenCL(Controller& controller, cl_context* context, cl_command_queue* command_queue,
                                 cl_program* program, cl_kernel* kernel, std::string method, Logger& logger)
 {
     auto platforms = controller.GetPlatforms();
-    if (PLATFORM_INDEX < 0 || PLATFORM_INDEX >= (int)platforms.size())
+    if (m_opt.platform_index < 0 || m_opt.platform_index >= (int)platforms.size())
         controller.CheckError(CL_INVALID_VALUE, "clGetPlatformIDs");
-    auto devices = controller.GetDevices(platforms[PLATFORM_INDEX]);
-    if (DEVICE_INDEX < 0 || DEVICE_INDEX >= (int)devices.size())
+    auto devices = controller.GetDevices(platforms[m_opt.platform_index]);
+    if (m_opt.device_index < 0 || m_opt.device_index >= (int)devices.size())
         controller.CheckError(CL_INVALID_DEVICE, "clGetDeviceIDs");
 
-    if (DISPLAY_TERMINAL_RESULTS) {
+    if (m_opt.display_terminal_results) {
         for (auto&& platform : platforms)
             controller.DisplayPlatformInformation(platform);
         std::ostringstream oss;
-        oss << "\nApplication will use:\nPLATFORM INDEX:\t" << PLATFORM_INDEX << "\nDEVICE INDEX:\t" << DEVICE_INDEX
+        oss << "\nApplication will use:\nPLATFORM INDEX:\t" << m_opt.platform_index << "\nDEVICE INDEX:\t" << m_opt.device_index
             << "\n"
             << std::endl;
         logger.log(oss.str(), Logger::LogLevel::INFO);
         oss.str("");
         char device_name[256] = {};
-        clGetDeviceInfo(devices[DEVICE_INDEX], CL_DEVICE_NAME, sizeof(device_name), device_name, NULL);
+        clGetDeviceInfo(devices[m_opt.device_index], CL_DEVICE_NAME, sizeof(device_name), device_name, NULL);
         oss << "Device name: " << device_name << std::endl;
         logger.log(oss.str(), Logger::LogLevel::INFO);
     }
@@ -82,17 +86,17 @@ void ProgramHandler::InitOpenCL(Controller& controller, cl_context* context, cl_
         exit(1);
     }
 
-    // KERNELS[method] = {image2d file, buffer file}; without an AddKernels entry fall back to the app's
+    // m_kernel_files[method] = {image2d file, buffer file}; without an AddKernels entry fall back to the app's
     // own naming scheme so the family is still recognisable
-    std::vector<std::string> files = KERNELS.count(method) ? KERNELS[method] : std::vector<std::string>{};
+    std::vector<std::string> files = m_kernel_files.count(method) ? m_kernel_files[method] : std::vector<std::string>{};
     if (files.size() < 2) {
         const std::string stem = method == "GRAYSCALE" ? "grayscale" : (method == "EDGE" ? "edge" : "gaussian");
         files = {stem + "_images.cl", stem + "_base.cl"};
     }
     std::string kernel_file;
     cl_bool image_support = CL_FALSE;
-    if (!BYPASS_IMAGE_SUPPORT) {
-        clGetDeviceInfo(devices[DEVICE_INDEX], CL_DEVICE_IMAGE_SUPPORT, sizeof(cl_bool), &image_support, nullptr);
+    if (!m_opt.bypass_image_support) {
+        clGetDeviceInfo(devices[m_opt.device_index], CL_DEVICE_IMAGE_SUPPORT, sizeof(cl_bool), &image_support, nullptr);
         if (image_support == CL_FALSE) {
             kernel_file = files[1];
             std::cout << "Device does not support images. Using buffers instead of image2D structures." << std::endl;
@@ -106,9 +110,9 @@ void ProgramHandler::InitOpenCL(Controller& controller, cl_context* context, cl_
     }
     controller.SetImageSupport(image_support);
 
-    *context = controller.CreateContext(platforms[PLATFORM_INDEX], devices);
-    *command_queue = controller.CreateCommandQueue(*context, devices[DEVICE_INDEX]);
-    *program = controller.CreateProgram(*context, devices[DEVICE_INDEX], kernel_file.c_str());
+    *context = controller.CreateContext(platforms[m_opt.platform_index], devices);
+    *command_queue = controller.CreateCommandQueue(*context, devices[m_opt.device_index]);
+    *program = controller.CreateProgram(*context, devices[m_opt.device_index], kernel_file.c_str());
     *kernel = controller.CreateKernel(*program, kernel_name.c_str());
 }
 
@@ -152,7 +156,7 @@ static bool read_ppm_rgba(const std::string& path, std::vector<unsigned char>* r
 }
 #endif
 
-void ProgramHandler::GetImageOpenCL(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width,
+void ProgramHandler::LoadFrame(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width,
                                     cl_int* height, Logger& logger)
 {
 #ifdef MI355_NO_OPENCV
@@ -164,7 +168,7 @@ void ProgramHandler::GetImageOpenCL(std::string image_path, std::vector<unsigned
         logger.log("Failed to load image", Logger::LogLevel::ERROR);
         return;
     }
-    if (DISPLAY_IMAGES)
+    if (m_opt.display_images)
         cv::imshow("Reference Image Window", image);
     cv::cvtColor(image, image, cv::COLOR_BGR2RGBA);
     *width = image.cols;
@@ -191,12 +195,12 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(
     std::vector<unsigned char> input_data;
     std::vector<unsigned char> function_output;
     width = height = 0;
-    GetImageOpenCL(image_path, &input_data, &width, &height, logger);
+    LoadFrame(image_path, &input_data, &width, &height, logger);
     const int which = method_index(method);
     const size_t npx = (size_t)width * height;
 
     double total_execution_time = 0.0, total_write_time = 0.0, total_kernel_time = 0.0, total_read_time = 0.0;
-    for (int i = 0; i < NUMBER_OF_ITERATIONS; i++) {
+    for (int i = 0; i < m_opt.iterations; i++) {
         std::vector<cl_ulong> ev;
         const auto t0 = std::chrono::high_resolution_clock::now();
         switch (which) {
@@ -212,7 +216,7 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(
             break;
         default:
             function_output = std::vector<unsigned char>(npx * 4);
-            controller.PerformCLGaussianBlur(GAUSSIAN_KERNEL_SIZE, GAUSSIAN_SIGMA, context, command_queue, kernel,
+            controller.PerformCLGaussianBlur(m_opt.gauss_k, m_opt.gauss_sigma, context, command_queue, kernel,
                                              &ev, &input_data, &function_output, width, height, logger);
             break;
         }
@@ -223,7 +227,7 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(
             total_write_time += (ev[1] - ev[0]) * 1e-6;
             total_kernel_time += (ev[3] - ev[2]) * 1e-6;
             total_read_time += (ev[5] - ev[4]) * 1e-6;
-            if (LOG_EVENTS) {
+            if (m_opt.log_events) {
                 static const char* names[6] = {"Write event start: ", "Write event end: ", "Kernel event start: ",
                                                "Kernel event end: ", "Read event start: ",  "Read event end: "};
                 for (int e = 0; e < 6; e++)
@@ -233,7 +237,7 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(
     }
     logger.log("OpenCL " + method + " conversion complete", Logger::LogLevel::INFO);
 
-    const double n = NUMBER_OF_ITERATIONS > 0 ? NUMBER_OF_ITERATIONS : 1;
+    const double n = m_opt.iterations > 0 ? m_opt.iterations : 1;
     avg_opencl_execution_time = total_execution_time / n;
     avg_opencl_kernel_write_time = total_write_time / n;
     avg_opencl_kernel_execution_time = total_kernel_time / n;
@@ -273,7 +277,7 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(Controller& controller,
     default:
         function_output = std::vector<unsigned char>(npx * 4);
         logger.log("Performing OpenCL Gaussian Blur...", Logger::LogLevel::INFO);
-        controller.PerformCLGaussianBlur(GAUSSIAN_KERNEL_SIZE, GAUSSIAN_SIGMA, context, command_queue, kernel,
+        controller.PerformCLGaussianBlur(m_opt.gauss_k, m_opt.gauss_sigma, context, command_queue, kernel,
                                          &profiling_events, &input_data, &function_output, width, height, logger);
         logger.log("OpenCL Gaussian Blur complete", Logger::LogLevel::INFO);
         break;
