@@ -14,8 +14,8 @@ static std::string query(cl_platform_id id, cl_platform_info name)
 }
 
 InfoPlatform::InfoPlatform(cl_platform_id id)
-    : m_info.profile(query(id, CL_PLATFORM_PROFILE)), m_info.name(query(id, CL_PLATFORM_NAME)),
-      m_info.version(query(id, CL_PLATFORM_VERSION)), m_info.vendor(query(id, CL_PLATFORM_VENDOR))
+    : m_info{query(id, CL_PLATFORM_PROFILE), query(id, CL_PLATFORM_NAME), query(id, CL_PLATFORM_VERSION),
+             query(id, CL_PLATFORM_VENDOR)}
 {
 }
 
