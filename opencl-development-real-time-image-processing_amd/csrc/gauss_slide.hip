@@ -409,7 +409,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
     const int strip = it.strip;
 
     const int q_lane = strip * lanes_out + lane - 1;  // this lane's pixel-quad column
-    const int q_load = clampi(q_lane, 0, quads - 1);   // replicated at the image border
+    // replicated at the image border; lanes right of the strip's right halo lane (never read by a storing lane)
+    // re-load the halo quad instead of the next strip's data
+    const int q_load = clampi(q_lane, 0, min(quads - 1, (strip + 1) * lanes_out));
     const int q_end = min((strip + 1) * lanes_out, quads);
     SlideLane L;
     L.left_of_image = q_lane < 0;

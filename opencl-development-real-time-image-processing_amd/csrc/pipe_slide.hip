@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
 
     const int q_lane = strip * lanes_out + lane - 1;
     const int quads = (w + 3) >> 2;
-    const int q_load = clampi(q_lane, 0, quads - 1);
+    const int q_load = clampi(q_lane, 0, min(quads - 1, (strip + 1) * lanes_out));  // idle lanes re-load the halo quad
     const bool left_of_image = q_lane < 0, right_of_image = q_lane >= quads;
     const bool edge_strip = (strip == 0) || (4 * (strip * lanes_out + 63) > w);  // wave-uniform
     const int x_lane = 4 * q_lane;
