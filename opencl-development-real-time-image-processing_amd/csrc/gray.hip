@@ -171,6 +171,7 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     // Rows of 4-pixel multiples take the strip-walk kernel with 4-row bands: measured on 256 x 4K frames, same
     // box, flat kernel 6.36 TB/s, strips of 4 / 8 / 16 / 32 rows 6.61 / 6.49 / 6.39 / 6.27 (1-channel output: 6.08
     // flat, 6.33 with 4 rows).  MI355_TUNE_GRAY_STRIP (tuning sweeps only): band height, 0 = flat kernel.
+    static const bool kStripForced = getenv("MI355_TUNE_GRAY_STRIP") != nullptr;  // tests: also on small shapes
     static const int kStripRows = [] {
         const char* e = getenv("MI355_TUNE_GRAY_STRIP");
         return e ? atoi(e) : 4;
@@ -178,7 +179,7 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     // ... and only where it pays: big batches (8 x 4K frames: -2.5 %, 256: +2 %) of rows that fill the 64-lane
     // strips (64-pixel-wide frames would leave 48 lanes idle: -23 %)
     const int strip_quads = w / 4, strip_n = (strip_quads + 63) / 64;
-    const bool strip_ok = (w & 3) == 0 && strip_quads * 100 >= strip_n * 64 * 93 && npx >= ((size_t)1 << 28);
+    const bool strip_ok = (w & 3) == 0 && (kStripForced || (strip_quads * 100 >= strip_n * 64 * 93 && npx >= ((size_t)1 << 28)));
     if (nquads && kStripRows > 0 && strip_ok) {
         const int quads = strip_quads, nstrips = strip_n;
         BandPlan plan;

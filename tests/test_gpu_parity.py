@@ -561,6 +561,7 @@ with pkg.Context(0) as ctx:
                 h.update(ctx.pipeline(img, k, s).tobytes())
             h.update(ctx.sobel(img).tobytes())
             h.update(ctx.gray1(img).tobytes())
+            h.update(ctx.gray(img).tobytes())
 print(h.hexdigest())
 """
 
@@ -578,7 +579,8 @@ def test_results_do_not_depend_on_the_band_plan():
                  {"MI355_TUNE_BAND_ROWS": "50", "MI355_TUNE_TAIL_ROWS": "3", "MI355_TUNE_TAIL_FRAC": "0.3"},
                  # kernels that normally serve big batches only: Sobel aligned strips, gray strips
                  {"MI355_TUNE_SOBEL_STRIP": "2", "MI355_TUNE_BAND_ROWS": "5"}, {"MI355_TUNE_SOBEL_STRIP": "2"},
-                 {"MI355_TUNE_SOBEL_STRIP": "0", "MI355_TUNE_LANES_OUT": "48"}):
+                 {"MI355_TUNE_SOBEL_STRIP": "0", "MI355_TUNE_LANES_OUT": "48"}, {"MI355_TUNE_GRAY_STRIP": "3"},
+                 {"MI355_TUNE_GRAY_STRIP": "0"}):
         env = dict(os.environ, **plan)
         out = subprocess.run([sys.executable, "-c", _BAND_PLAN_SCRIPT, root], env=env, capture_output=True,
                              text=True, timeout=300)
