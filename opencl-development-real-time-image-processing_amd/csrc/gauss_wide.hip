@@ -61,7 +61,14 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
     for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
-    float acc[K][2 * NCH] = {};
+    // Ring of the last K input rows as packed halves (a byte value is exact in fp16): {pixel 0, pixel 1} of one
+    // channel per VGPR, K x NCH registers instead of the K x 2 x NCH fp32 accumulators of the first version —
+    // at k = 17 that is 51 instead of 102: 139 VGPRs instead of 223, 3 waves per SIMD instead of 2.  The vertical sums of an
+    // output row are formed when its window is complete, by v_fma_mix_f32 (fp32 multiply-add with an fp16 source,
+    // converted exactly): the same canonical chain, the same bits.  v_fma_mix issues at ~3 cycles instead of 2
+    // (tools/probe_valu.hip), which the doubled occupancy more than pays for.
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 ring[K][NCH];
     // horizontal pass: output pixel e of this lane reads strip pixels 2*lane + e - R + t = row entries
     // 2*lane + e + t, t = 0..K-1: one base pointer per lane, immediate offsets per tap
     // The row is stored as two planes, even and odd entries (entry e lives in plane e & 1 at index e >> 1), so
@@ -87,23 +94,26 @@ __device__ __forceinline__ bool gauss_wide_band(const WideLane& L, const float (
                     return false;
             }
 #pragma unroll
-            for (int px = 0; px < 2; px++) {
-                float f[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; c++)
-                    f[c] = (float)((p[px] >> (8 * c)) & 0xFFu);
-#pragma unroll
-                for (int j = 0; j < K; j++) {
-                    const int s = (u - j + K) % K;
-#pragma unroll
-                    for (int c = 0; c < NCH; c++)
-                        acc[s][px * NCH + c] =
-                            (j == 0) ? wv[0] * f[c] : __builtin_fmaf(wv[j], f[c], acc[s][px * NCH + c]);
-                }
-            }
+            for (int c = 0; c < NCH; c++)
+                ring[u][c] = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz((float)((p.x >> (8 * c)) & 0xFFu),
+                                                                           (float)((p.y >> (8 * c)) & 0xFFu)));
             const int m = i - 2 * R;
             if (m >= 0) {  // wave-uniform: the first 2R rows of a band finish no output row
-                const float* v = acc[(u + 1) % K];
+                // canonical vertical chain, top tap first: the oldest row of the ring is slot u + 1.  (The first
+                // step is written as fma(w0, x, +0) = w0 * x so that it too takes the fp16 source directly.)
+                float v[2 * NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    float a0 = __builtin_fmaf(wv[0], (float)ring[(u + 1) % K][c].x, 0.0f);
+                    float a1 = __builtin_fmaf(wv[0], (float)ring[(u + 1) % K][c].y, 0.0f);
+#pragma unroll
+                    for (int j = 1; j < K; j++) {
+                        a0 = __builtin_fmaf(wv[j], (float)ring[(u + 1 + j) % K][c].x, a0);
+                        a1 = __builtin_fmaf(wv[j], (float)ring[(u + 1 + j) % K][c].y, a1);
+                    }
+                    v[c] = a0;
+                    v[NCH + c] = a1;
+                }
                 // this lane's pixels are entries R + 2*lane and R + 2*lane + 1
                 L.vr[(R & 1) * kPlane + (R >> 1) + L.lane] = f32x4{v[0], v[1], v[2], NCH == 4 ? v[NCH - 1] : 0.0f};
                 L.vr[((R + 1) & 1) * kPlane + ((R + 1) >> 1) + L.lane] =

@@ -41,6 +41,10 @@ PROBE(k_floor, "v_floor_f32 %0, %1\n v_floor_f32 %1, %2\n v_floor_f32 %2, %3\n v
 PROBE(k_lshl_or, "v_lshl_or_b32 %0, %1, 8, %2\n v_lshl_or_b32 %1, %2, 8, %3\n v_lshl_or_b32 %2, %3, 8, %4\n v_lshl_or_b32 %3, %4, 8, %5\n v_lshl_or_b32 %4, %5, 8, %6\n v_lshl_or_b32 %5, %6, 8, %7\n v_lshl_or_b32 %6, %7, 8, %0\n v_lshl_or_b32 %7, %0, 8, %1\n")
 PROBE(k_perm, "v_perm_b32 %0, %1, %2, %8\n v_perm_b32 %1, %2, %3, %8\n v_perm_b32 %2, %3, %4, %8\n v_perm_b32 %3, %4, %5, %8\n v_perm_b32 %4, %5, %6, %8\n v_perm_b32 %5, %6, %7, %8\n v_perm_b32 %6, %7, %0, %8\n v_perm_b32 %7, %0, %1, %8\n")
 
+PROBE(k_fma_mix_lo, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %2, %3, %4, %2 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %4, %5, %6, %4 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %5, %6, %7, %5 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %6, %7, %0, %6 op_sel_hi:[0,1,0]\n v_fma_mix_f32 %7, %0, %1, %7 op_sel_hi:[0,1,0]\n")
+PROBE(k_fma_mix_hi, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %2, %3, %4, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %4, %5, %6, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %5, %6, %7, %5 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %6, %7, %0, %6 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %7, %0, %1, %7 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n")
+PROBE(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %1, %2, %3\n v_cvt_pkrtz_f16_f32 %2, %3, %4\n v_cvt_pkrtz_f16_f32 %3, %4, %5\n v_cvt_pkrtz_f16_f32 %4, %5, %6\n v_cvt_pkrtz_f16_f32 %5, %6, %7\n v_cvt_pkrtz_f16_f32 %6, %7, %0\n v_cvt_pkrtz_f16_f32 %7, %0, %1\n")
+
 template <typename K> void run(const char* name, K kern, uint64_t* d)
 {
     for (int waves_per_simd : {1, 2, 4}) {
@@ -95,6 +99,9 @@ int main()
     run("v_floor_f32", k_floor, d);
     run("v_lshl_or_b32", k_lshl_or, d);
     run("v_perm_b32", k_perm, d);
+    run("v_fma_mix_f32 lo", k_fma_mix_lo, d);
+    run("v_fma_mix_f32 hi", k_fma_mix_hi, d);
+    run("v_cvt_pkrtz_f16", k_cvt_pkrtz, d);
     for (int mode : {0, 1}) for (int w : {1, 2, 4}) {
         hipMemset(d, 0, 16 * 8 * 256);
         hipLaunchKernelGGL(k_pk, dim3(256), dim3(256 * w), 0, 0, d, 1.0f, mode); hipDeviceSynchronize();
