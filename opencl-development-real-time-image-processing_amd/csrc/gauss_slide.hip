@@ -483,9 +483,9 @@ bool slide_plan(int w, int h, int nframes, StripPlan* sp, BandPlan* plan)
     //   k = 5: 24 rows (6.10 / 5.47; adaptive 6.10 / 5.05) — warm-up rows skip the horizontal pass, so short
     //          bands cost little arithmetic; the general 4-channel pass alone would prefer ~64 rows (-4 % here)
     //   k >= 7: VALU-bound, the 2R warm-up rows hurt: tall adaptive bands + short-band tail
-    return (K == 3)   ? make_band_plan(h, sp->nstrips, nframes, 5, 12, 12, 12, 0.0, plan)
-           : (K == 5) ? make_band_plan(h, sp->nstrips, nframes, 4, 24, 24, 24, 0.0, plan)
-                      : make_band_plan(h, sp->nstrips, nframes, 3, 96, 270, 40, 0.1, plan);
+    return (K == 3)   ? make_band_plan(h, sp->nstrips, nframes, 5, 12, 12, 12, 0.0, 6, plan)
+           : (K == 5) ? make_band_plan(h, sp->nstrips, nframes, 4, 24, 24, 24, 0.0, 12, plan)
+                      : make_band_plan(h, sp->nstrips, nframes, 3, 96, 270, 40, 0.1, 4 * R + 4, plan);
 }
 
 template <int R>

@@ -221,7 +221,7 @@ bool wide_plan(int w, int h, int nframes, int& pairs, int& nstrips, int& lanes_o
     const int lanes_max = 64 - 2 * H;
     nstrips = (pairs + lanes_max - 1) / lanes_max;
     lanes_out = (pairs + nstrips - 1) / nstrips;
-    return make_band_plan(h, nstrips, nframes, 2, 128, 360, 48, 0.1, plan);
+    return make_band_plan(h, nstrips, nframes, 2, 128, 360, 48, 0.1, 4 * R, plan);
 }
 
 template <int R>

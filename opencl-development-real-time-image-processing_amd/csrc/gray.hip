@@ -183,7 +183,7 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     if (nquads && kStripRows > 0 && strip_ok) {
         const int quads = strip_quads, nstrips = strip_n;
         BandPlan plan;
-        if (!make_band_plan(h, nstrips, nframes, 8, kStripRows, kStripRows, kStripRows, 0.0, &plan))
+        if (!make_band_plan(h, nstrips, nframes, 8, kStripRows, kStripRows, kStripRows, 0.0, 0, &plan))
             return hipErrorInvalidValue;
         const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kSlideWavesPerBlock * 64);
         if (one_channel)

@@ -272,7 +272,7 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     // instructions changed nothing), short bands keep the rows that are in flight close together in memory.
     BandPlan plan;
     constexpr int kRows = (R == 1) ? 16 : (R == 2 ? 24 : 40);
-    if (!make_band_plan(h, sp.nstrips, nframes, 8, kRows, kRows, kRows, 0.0, &plan))
+    if (!make_band_plan(h, sp.nstrips, nframes, 8, kRows, kRows, kRows, 0.0, kRows / 2, &plan))
         return hipErrorInvalidValue;
     PWeights<K> wts;
     double wsum = 0.0;

@@ -58,8 +58,12 @@ inline StripPlan make_strip_plan(int w, int lanes_pref = 0)
 }
 
 // waves_per_simd: occupancy of the kernel (from its VGPR count); rows_min/rows_max: clamp of the tall bands
+// rows_small: the band height is halved, down to this floor, while the launch has fewer than ~2800 work items —
+// a launch too small to occupy the chip (one or a few frames) is cut finer.  Measured on ONE 4K frame: Gaussian
+// k = 5 24-row bands 19 us, 12-row bands 16 us; k = 7 96 rows 54 us, 24 rows 26 us; k = 17 128 rows 95 us, 32 rows
+// 55 us; Sobel 16 -> 8 rows +6 %; pipeline 24 -> 12 rows +17 %.  The floor is about twice the warm-up rows.
 inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, int rows_min, int rows_max,
-                           int rows_tail, double tail_frac, BandPlan* out)
+                           int rows_tail, double tail_frac, int rows_small, BandPlan* out)
 {
     const double resident = 256.0 * 4.0 * waves_per_simd;
     double rows = (double)h * nstrips * nframes / (10.0 * resident);
@@ -78,10 +82,7 @@ inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, 
                 tail_frac = atof(e);
         }
     } tune;
-    // a launch too small to occupy the chip (one or two frames) is cut finer: measured on ONE 4K frame, Gaussian
-    // 24-row bands 19 us, 12-row bands 16 us; Sobel 16 -> 8 rows +6 %; pipeline 24 -> 12 rows +17 %
-    // (only the kernels with fixed, short bands ask for this: for them warm-up rows are cheap)
-    while (rows_min == rows_max && rows_big >= 8 &&
+    while (rows_small > 0 && rows_big / 2 >= rows_small &&
            (size_t)nstrips * ((h + rows_big - 1) / rows_big) * nframes < 2800)
         rows_big /= 2;
     if (tune.band_rows > 0)

@@ -307,7 +307,7 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
         (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0) {
         const int quads = w / 4, nstrips = (quads + 63) / 64;
         BandPlan plan;
-        if (!make_band_plan(h, nstrips, nframes, 8, 16, 16, 16, 0.0, &plan))
+        if (!make_band_plan(h, nstrips, nframes, 8, 16, 16, 16, 0.0, 8, &plan))
             return hipErrorInvalidValue;
         hipLaunchKernelGGL(sobel_strip_kernel, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
                            stream, d_in, d_out, quads, h, nstrips, plan);
@@ -320,7 +320,7 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
     // wants many short work items — measured at steady clocks on 256 x 4K frames: 16-row bands 5.2 TB/s,
     // 32 rows 5.0, 64 rows 4.5, 128 rows 4.2
     BandPlan plan;
-    if (!make_band_plan(h, sp.nstrips, nframes, 8, 16, 16, 16, 0.0, &plan))
+    if (!make_band_plan(h, sp.nstrips, nframes, 8, 16, 16, 16, 0.0, 8, &plan))
         return hipErrorInvalidValue;
     const bool ragged = (w & 3) != 0 || (reinterpret_cast<uintptr_t>(d_in) & 15u) != 0 ||
                         (reinterpret_cast<uintptr_t>(d_out) & 3u) != 0;
