@@ -102,6 +102,9 @@ def load_library():
         "mi355_checksum_dev": [_vp, _vp, ctypes.c_size_t, ctypes.c_uint64, _u64p],
         "mi355_selftest": [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
         "mi355_dev_alloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
+        "mi355_pool_alloc": [_vp, _ci, _ci, _ci, _ci, _ci, ctypes.c_float, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                             _f32p],
+        "mi355_pool_free": [_vp, _vp, _vp],
         "mi355_dev_free": [_vp, _vp],
         "mi355_copy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
         "mi355_copy_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
@@ -313,6 +316,20 @@ class Context:
         a, b = ctypes.c_uint32(0), ctypes.c_uint32(0)
         _check("mi355_selftest", self._lib.mi355_selftest(self._h, ctypes.byref(a), ctypes.byref(b)), self._h)
         return a.value, b.value
+
+    def pool_alloc(self, filt, w, h, nframes, k=5, sigma=1.5, tries=4):
+        """(d_in, d_out, probe_ms): input (0xFF-filled) and output frame pools, the output pool placed by a short
+        search over physical placements (see mi355_pool_alloc); release with pool_free."""
+        a, b = _vp(), _vp()
+        ms = (ctypes.c_float * max(1, tries))()
+        rc = self._lib.mi355_pool_alloc(self._h, int(filt), int(w), int(h), int(nframes), int(k), float(sigma),
+                                        int(tries), ctypes.byref(a), ctypes.byref(b), ms)
+        _check("mi355_pool_alloc", rc, self._h)
+        return a.value, b.value, [float(x) for x in ms][:max(1, tries)]
+
+    def pool_free(self, d_in, d_out):
+        _check("mi355_pool_free", self._lib.mi355_pool_free(self._h, _vp(int(d_in or 0)), _vp(int(d_out or 0))),
+               self._h)
 
     def alloc(self, nbytes):
         p = _vp()

@@ -45,6 +45,8 @@ def test_argument_validation_needs_no_gpu(pkg):
     assert lib.mi355_gray_rgba8(None, None, None, 4, 4, None) == -1
     assert lib.mi355_filter_dev(None, 0, None, None, 4, 4, 1, 0, 0.0) == -1
     assert lib.mi355_ctx_destroy(None) == -1
+    assert lib.mi355_pool_alloc(None, 2, 4, 4, 1, 5, 1.5, 3, None, None, None) == -1
+    assert lib.mi355_pool_free(None, None, None) == -1
     assert lib.mi355_strerror(-1) == b"bad argument"
     assert lib.mi355_strerror(0) == b"ok"
     n = ctypes.c_int(-5)

@@ -640,3 +640,23 @@ def test_sobel_stays_close_to_the_reference_opencl_kernel(ctx, oracle):
     cl_kernel = np.floor(mag.astype(np.float32) * np.float32(255)).astype(np.float64)
     d = np.abs(got[1:-1, 1:-1] - cl_kernel)
     assert d.max() <= 6 and d.mean() < 1.0, (d.max(), d.mean())
+
+
+def test_pool_alloc_with_placement_search(ctx, pkg, oracle):
+    """mi355_pool_alloc: the pools it hands out are ordinary device buffers (the filter run on them equals the
+    oracle), every probed candidate reports a positive time, and tries = 1 is a plain allocation."""
+    w, h, n = 500, 300, 3
+    frames = rand_rgba(h, w, seed=77, n=n)
+    for tries in (1, 3):
+        d_in, d_out, ms = ctx.pool_alloc(pkg.FILTER_SOBEL, w, h, n, tries=tries)
+        assert d_in and d_out and len(ms) == tries
+        if tries > 1:
+            assert ms[0] > 0 and all(m > 0 or m == -1.0 for m in ms)
+        ctx.h2d(d_in, frames)
+        ctx.filter_dev(pkg.FILTER_SOBEL, d_in, d_out, w, h, n)
+        got = np.empty((n, h, w), np.uint8)
+        ctx.d2h(got, d_out)
+        assert np.array_equal(got, np.stack([oracle.sobel_rgba(f) for f in frames]))
+        ctx.pool_free(d_in, d_out)
+    with pytest.raises(pkg.Mi355Error):
+        ctx.pool_alloc(pkg.FILTER_GAUSS, w, h, n, k=4, sigma=1.0)
