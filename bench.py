@@ -56,9 +56,8 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
-    p.add_argument("--pool-gap-gb", type=float, default=-1.0,
-                   help="-1 (default): probe a few placements of the output pool and keep the fastest; >= 0: allocate "
-                        "the output frames exactly this many GB after the input frames, no probing")
+    p.add_argument("--pool-candidates", type=int, default=6,
+                   help="output pools allocated and probed before the warm-up, the fastest is kept (1 = plain allocation)")
     p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
                    "many frames (>= --frames) but process only --frames of them")
     return p.parse_args()
@@ -143,18 +142,12 @@ def main():
         d_in[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
 
     # Pool placement: where the two frame pools land physically decides up to 8 % of the
-    # streaming rate on this chip, and an allocation cannot be steered, only re-drawn.  So the output pool is
-    # allocated at a few different distances behind the input pool (a spacer that is released again at once), each
-    # placement is probed with a handful of launches of the very filter to be measured, and the fastest is kept.
+    # streaming rate on this chip, and an allocation cannot be steered, only re-drawn.  So several candidate output
+    # pools are allocated side by side (all alive at once, hence all in different places), each is probed with a
+    # handful of launches of the very filter to be measured, the fastest is kept and the others are freed.
     # This is set-up: it happens before the warm-up, outside the timed region, and its probes are reported.
-    def alloc_out(gap_gb):
-        spacer = torch.empty(int(gap_gb * 2**30), dtype=torch.uint8, device=dev) if gap_gb > 0 else None
-        out = torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev)
-        del spacer
-        return out
-
-    def probe(out_t, launches=6):
-        for _ in range(3):
+    def probe(out_t, launches=8):
+        for _ in range(4):
             ctx.filter_dev(filt, d_in.data_ptr(), out_t.data_ptr(), w, h, F, args.k, args.sigma)
         torch.cuda.synchronize(dev)
         ctx.timer_begin()
@@ -163,25 +156,18 @@ def main():
         return ctx.timer_end() / launches
 
     pool_probes = []
-    if args.pool_gap_gb >= 0:            # explicit gap, no search (0 = plain back-to-back allocation)
-        d_out_full = alloc_out(args.pool_gap_gb)
-        torch.cuda.empty_cache()
+    out_bytes = FA * h * w * out_bpp
+    free_b, _total = torch.cuda.mem_get_info(dev)
+    ncand = max(1, min(args.pool_candidates, int((free_b - (24 << 30)) // max(out_bytes, 1))))
+    cands = [torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev) for _ in range(ncand)]
+    if ncand > 1:
+        pool_probes = [round(probe(c), 4) for c in cands]
+        keep = min(range(ncand), key=lambda i: pool_probes[i])
     else:
-        free_b, _total = torch.cuda.mem_get_info(dev)
-        best = None
-        for gap in (0, 64, 100, 160):
-            if (gap + 24) * 2**30 + 2 * d_in.numel() > free_b:
-                continue
-            cand = alloc_out(gap)
-            torch.cuda.empty_cache()     # the spacer goes back to the driver; the best placement so far stays put
-            ms = probe(cand)
-            pool_probes.append({"gap_gb": gap, "probe_ms": round(ms, 4)})
-            if best is None or ms < best[0]:
-                best = (ms, cand)        # (drops the previous best)
-            del cand
-            torch.cuda.empty_cache()     # a dropped candidate must not be handed out again by torch's cache
-        d_out_full = best[1]
-        del best
+        keep = 0
+    d_out_full = cands[keep]
+    del cands
+    torch.cuda.empty_cache()
     d_out = d_out_full[:F]
 
     # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes

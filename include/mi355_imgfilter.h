@@ -195,12 +195,12 @@ int mi355_dev_alloc(mi355_ctx* ctx, size_t nbytes, void** d_ptr);
 /* Frame pools with a placement search.  On MI355X the PHYSICAL placement of a streaming kernel's input and output
  * buffers decides up to 8 % of its rate (the same command reads 5.5 or 6.0 TB/s from one process to the next), and
  * an allocation cannot be steered, only re-drawn.  This call allocates the input pool
- * (nframes x w x h RGBA, filled with 0xFF) and then up to `tries` candidate output pools at different distances
- * behind it (0, 64, 100, 160, 32, 128 GB: a spacer that is released again at once), runs a few launches of
- * `filter` on each, keeps the fastest and frees the others.  tries <= 1: plain allocation, no probing.  probe_ms
- * (optional, `tries` floats): average launch time per candidate, -1 for candidates skipped for lack of memory.
- * Synchronises the context's stream.  Release with mi355_pool_free.  (Replaces nothing in the reference, which
- * allocates and frees its buffers per frame, RT/src/Controller.cpp:646-652,742-744.) */
+ * (nframes x w x h RGBA, filled with 0xFF) and up to `tries` (<= 16) candidate output pools side by side — all
+ * alive at once, hence all in different places; fewer if memory runs short — runs a few launches of `filter` on
+ * each, keeps the fastest and frees the others.  tries <= 1: plain allocation, no probing.  probe_ms (optional,
+ * `tries` floats): average launch time per candidate, -1 for candidates that were not allocated.  Synchronises
+ * the context's stream.  Release with mi355_pool_free.  (Replaces nothing in the reference, which allocates and
+ * frees its buffers per frame, RT/src/Controller.cpp:646-652,742-744.) */
 int mi355_pool_alloc(mi355_ctx* ctx, int filter, int w, int h, int nframes, int k, float sigma, int tries,
                      void** d_in, void** d_out, float* probe_ms);
 int mi355_pool_free(mi355_ctx* ctx, void* d_in, void* d_out);

@@ -834,8 +834,7 @@ MI355_API int mi355_pool_alloc(mi355_ctx* ctx, int filter, int w, int h, int nfr
         return MI355_ERR_BAD_ARG;
     if (filter_needs_gauss(filter) && (!valid_k(k) || !valid_sigma(sigma)))
         return MI355_ERR_BAD_ARG;
-    static const size_t kGapGb[] = {0, 64, 100, 160, 32, 128};
-    const int ncand = tries < 1 ? 1 : (tries > 6 ? 6 : tries);
+    constexpr int kMaxCand = 16;
     for (int i = 0; probe_ms && i < tries; i++)
         probe_ms[i] = -1.0f;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -845,79 +844,68 @@ MI355_API int mi355_pool_alloc(mi355_ctx* ctx, int filter, int w, int h, int nfr
         return MI355_ERR_NOMEM;
     // defined, opaque input (A = 255): the placement probe then times the path real frames take
     hipError_t e = hipMemsetAsync(in, 0xFF, in_bytes, ctx->stream);
-    void* best = nullptr;
-    float best_ms = 0.0f;
     int rc = (e == hipSuccess) ? MI355_OK : MI355_ERR_HIP;
-    for (int i = 0; rc == MI355_OK && i < ncand; i++) {
+    if (e != hipSuccess)
+        ctx->last_hip = (int)e;
+
+    // all candidates alive at once, hence all in different places; stop early when memory runs short
+    void* cand[kMaxCand] = {};
+    int ncand = 0;
+    const int want = tries < 1 ? 1 : (tries > kMaxCand ? kMaxCand : tries);
+    while (rc == MI355_OK && ncand < want) {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
-            free_b = 0;
-        const size_t gap = kGapGb[i] << 30;
-        if (gap + out_bytes + ((size_t)1 << 30) > free_b && i > 0)
-            continue;  // not enough room for this distance: skip the candidate
-        void* spacer = nullptr;
-        if (gap && hipMalloc(&spacer, gap) != hipSuccess)
-            continue;
-        void* out = nullptr;
-        const hipError_t eo = hipMalloc(&out, out_bytes);
-        if (spacer)
-            (void)hipFree(spacer);
-        if (eo != hipSuccess) {
-            if (i == 0)
-                rc = MI355_ERR_NOMEM;
-            continue;
-        }
-        if (ncand == 1) {
-            best = out;
+        if (ncand > 0 && (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < out_bytes + ((size_t)8 << 30)))
+            break;
+        if (hipMalloc(&cand[ncand], out_bytes) != hipSuccess) {
+            cand[ncand] = nullptr;
             break;
         }
+        ncand++;
+    }
+    if (rc == MI355_OK && ncand == 0)
+        rc = MI355_ERR_NOMEM;
+    int keep = 0;
+    float best_ms = 0.0f;
+    for (int i = 0; rc == MI355_OK && ncand > 1 && i < ncand; i++) {
         float ms = 0.0f;
-        for (int l = 0; rc == MI355_OK && l < 3 + 6; l++) {
-            if (l == 3 && (e = hipEventRecord(ctx->t0, ctx->stream)) != hipSuccess) {
+        for (int l = 0; rc == MI355_OK && l < 4 + 8; l++) {
+            if (l == 4 && (e = hipEventRecord(ctx->t0, ctx->stream)) != hipSuccess) {
                 ctx->last_hip = (int)e;
                 rc = MI355_ERR_HIP;
                 break;
             }
-            rc = dispatch_dev(ctx, filter, in, out, w, h, nframes, k, sigma);
+            rc = dispatch_dev(ctx, filter, in, cand[i], w, h, nframes, k, sigma);
         }
-        if (rc == MI355_OK) {
-            e = hipEventRecord(ctx->t1, ctx->stream);
-            if (e == hipSuccess)
-                e = hipEventSynchronize(ctx->t1);
-            if (e == hipSuccess)
-                e = hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
-            if (e != hipSuccess) {
-                ctx->last_hip = (int)e;
-                rc = MI355_ERR_HIP;
-            }
-        }
-        if (rc != MI355_OK) {
-            (void)hipFree(out);
+        if (rc != MI355_OK)
+            break;
+        e = hipEventRecord(ctx->t1, ctx->stream);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(ctx->t1);
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
+        if (e != hipSuccess) {
+            ctx->last_hip = (int)e;
+            rc = MI355_ERR_HIP;
             break;
         }
-        ms /= 6.0f;
-        if (probe_ms && i < tries)
+        ms /= 8.0f;
+        if (probe_ms)
             probe_ms[i] = ms;
-        if (!best || ms < best_ms) {
-            if (best)
-                (void)hipFree(best);  // (hipFree waits for the device)
-            best = out;
+        if (i == 0 || ms < best_ms) {
             best_ms = ms;
-        } else {
-            (void)hipFree(out);
+            keep = i;
         }
     }
-    if (rc == MI355_OK && !best)
-        rc = MI355_ERR_NOMEM;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < ncand; i++)
+        if (rc != MI355_OK || i != keep)
+            (void)hipFree(cand[i]);
     if (rc != MI355_OK) {
-        if (best)
-            (void)hipFree(best);
         (void)hipFree(in);
         return rc;
     }
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     *d_in = in;
-    *d_out = best;
+    *d_out = cand[keep];
     return MI355_OK;
 }
 
