@@ -22,6 +22,20 @@ for f in find("trace/**/*kernel_trace.csv"):
         agg[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print("%-90s n=%4d avg=%10.2f min=%10.2f max=%10.2f" % (k[:90], len(v), sum(v) / len(v), min(v), max(v)))
+    # the timed region of bench.py = the LAST `steps` dispatches of the dominant kernel (before them come the
+    # placement probes and the warm-up launches); bench.py's own HIP-event figure is in trace.log
+    import json
+    import re
+    log = os.path.join(out, "trace.log")
+    m = re.search(r'\{"metric".*\}', open(log).read()) if os.path.exists(log) else None
+    if m and agg:
+        line = json.loads(m.group(0))
+        steps = int(line["steps"])
+        dom = max(agg.items(), key=lambda kv: sum(kv[1]))
+        if len(dom[1]) >= steps:
+            tail = dom[1][-steps:]
+            print("timed region: last %d dispatches of %s: avg=%.2f us (rocprofv3 trace)  |  bench.py HIP events, same "
+                  "process: %.2f us" % (steps, dom[0][:60], sum(tail) / len(tail), 1e3 * line["roofline"]["avg_launch_ms"]))
     for r in rows[:1]:
         print("columns:", ",".join(r.keys()))
     regs = {}
