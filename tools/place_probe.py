@@ -1,5 +1,5 @@
-"""Where in the 288 GB do the two frame pools sit, and does it matter?  One process; the output pool (or both) is
-allocated behind spacers of different sizes; every placement is timed with the headline kernel."""
+"""Does the physical placement of the two frame pools matter, and of which one?  One process: 4 candidate input pools
+and 6 candidate output pools allocated side by side (in that order), every pair timed with the headline kernel."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,9 +10,10 @@ dev = torch.device("cuda", 0)
 ctx = pkg.Context(0, stream=torch.cuda.current_stream(dev).cuda_stream)
 w, h, F = 3840, 2160, 256
 nb = F * h * w * 4
+filt = {"gauss": pkg.FILTER_GAUSS, "gray": pkg.FILTER_GRAY}[sys.argv[1] if len(sys.argv) > 1 else "gauss"]
 
 
-def measure(a, b, filt=pkg.FILTER_GAUSS, steps=12):
+def measure(a, b, steps=10):
     for _ in range(4):
         ctx.filter_dev(filt, a, b, w, h, F, 5, 1.5)
     torch.cuda.synchronize()
@@ -22,28 +23,11 @@ def measure(a, b, filt=pkg.FILTER_GAUSS, steps=12):
     return 2 * nb / (ctx.timer_end() / steps) / 1e6
 
 
-def place(pre_gb, mid_gb):
-    pre = torch.empty(int(pre_gb * 2**30), dtype=torch.uint8, device=dev) if pre_gb else None
-    a = torch.empty(nb, dtype=torch.uint8, device=dev)
-    mid = torch.empty(int(mid_gb * 2**30), dtype=torch.uint8, device=dev) if mid_gb else None
-    b = torch.empty(nb, dtype=torch.uint8, device=dev)
-    del pre, mid
-    torch.cuda.empty_cache()
-    ctx.synth_dev(a.data_ptr(), w, h, F)
-    g = measure(a.data_ptr(), b.data_ptr())
-    del a, b
-    torch.cuda.empty_cache()
-    return g
-
-
-print("rows: GB before the input pool; columns: GB between the pools")
-gaps = [0, 16, 32, 48, 64, 80, 100, 128, 160, 200]
-print("      " + " ".join("%5d" % g for g in gaps))
-for pre in (0, 32, 64, 100):
-    row = []
-    for mid in gaps:
-        if pre + mid + 20 > 260:
-            row.append("    -")
-            continue
-        row.append("%5.0f" % place(pre, mid))
-    print("%5d " % pre + " ".join(row), flush=True)
+ins = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(4)]
+outs = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(6)]
+for t in ins:
+    ctx.synth_dev(t.data_ptr(), w, h, F)
+measure(ins[0].data_ptr(), outs[0].data_ptr(), 30)  # clocks up
+print("rows: input pool #, columns: output pool # (allocation order: in0..in3, out0..out5); GB/s")
+for i, a in enumerate(ins):
+    print("in%d  " % i + " ".join("%5.0f" % measure(a.data_ptr(), b.data_ptr()) for b in outs), flush=True)
