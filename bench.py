@@ -56,7 +56,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
-    p.add_argument("--pool-candidates", type=int, default=6,
+    p.add_argument("--pool-candidates", type=int, default=12,
                    help="output pools allocated and probed before the warm-up, the fastest is kept (1 = plain allocation)")
     p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
                    "many frames (>= --frames) but process only --frames of them")
@@ -159,12 +159,20 @@ def main():
     out_bytes = FA * h * w * out_bpp
     free_b, _total = torch.cuda.mem_get_info(dev)
     ncand = max(1, min(args.pool_candidates, int((free_b - (24 << 30)) // max(out_bytes, 1))))
-    cands = [torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev) for _ in range(ncand)]
-    if ncand > 1:
-        pool_probes = [round(probe(c), 4) for c in cands]
-        keep = min(range(ncand), key=lambda i: pool_probes[i])
-    else:
-        keep = 0
+    # candidates are added one at a time and stay allocated while the search runs; it stops early once one of them
+    # is clearly in the fast state (>= 4.5 % quicker than the slowest seen: the two states are ~7 % apart)
+    cands = []
+    for _ in range(ncand):
+        cands.append(torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev))
+        if ncand == 1:
+            break
+        if not pool_probes:              # clocks up before the first probe, or it reads slow for the wrong reason
+            for _ in range(20):
+                ctx.filter_dev(filt, d_in.data_ptr(), cands[0].data_ptr(), w, h, F, args.k, args.sigma)
+        pool_probes.append(round(probe(cands[-1]), 4))
+        if pool_probes[-1] < 0.955 * max(pool_probes):
+            break
+    keep = min(range(len(pool_probes)), key=lambda i: pool_probes[i]) if pool_probes else 0
     d_out_full = cands[keep]
     del cands
     torch.cuda.empty_cache()
