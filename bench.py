@@ -159,8 +159,7 @@ def main():
     out_bytes = FA * h * w * out_bpp
     free_b, _total = torch.cuda.mem_get_info(dev)
     ncand = max(1, min(args.pool_candidates, int((free_b - (24 << 30)) // max(out_bytes, 1))))
-    # candidates are added one at a time and stay allocated while the search runs; it stops early once one of them
-    # is clearly in the fast state (>= 4.5 % quicker than the slowest seen: the two states are ~7 % apart)
+    # candidates are added one at a time and stay allocated while the search runs
     cands = []
     for _ in range(ncand):
         cands.append(torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev))
@@ -170,7 +169,9 @@ def main():
             for _ in range(20):
                 ctx.filter_dev(filt, d_in.data_ptr(), cands[0].data_ptr(), w, h, F, args.k, args.sigma)
         pool_probes.append(round(probe(cands[-1]), 4))
-        if pool_probes[-1] < 0.955 * max(pool_probes):
+        # there are more than two states (gray on one box: 6.08 / 6.31 / 6.72 / 6.79 TB/s over six pools), so the
+        # search only stops early when it has seen enough pools AND holds one clearly out of the slow state
+        if len(pool_probes) >= 6 and min(pool_probes) < 0.955 * max(pool_probes):
             break
     keep = min(range(len(pool_probes)), key=lambda i: pool_probes[i]) if pool_probes else 0
     d_out_full = cands[keep]
