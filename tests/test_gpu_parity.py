@@ -660,3 +660,33 @@ def test_pool_alloc_with_placement_search(ctx, pkg, oracle):
         ctx.pool_free(d_in, d_out)
     with pytest.raises(pkg.Mi355Error):
         ctx.pool_alloc(pkg.FILTER_GAUSS, w, h, n, k=4, sigma=1.0)
+
+
+def test_two_contexts_on_two_host_threads(pkg, oracle):
+    """A context is single-threaded, but two contexts (own streams, own pools, own coefficient caches) must be usable
+    from two host threads at once — the library keeps no mutable global state."""
+    import threading
+    frames = [rand_rgba(97, 252, seed=s) for s in (1, 2)]
+    want = [(oracle.gauss_rgba(f, 5, 1.5), oracle.sobel_rgba(f), oracle.gray_rgba_1ch(f)) for f in frames]
+    errors = []
+
+    def worker(idx):
+        try:
+            with pkg.Context(0) as c:
+                for it in range(25):
+                    g = c.gauss(frames[idx], 5, 1.5)
+                    assert np.abs(g.astype(np.int16) - want[idx][0].astype(np.int16)).max() <= 1
+                    assert np.array_equal(c.sobel(frames[idx]), want[idx][1])
+                    assert np.array_equal(c.gray1(frames[idx]), want[idx][2])
+                    if it % 5 == 0:  # the fused kernel == the three calls chained (FAST arithmetic)
+                        chained = c.sobel(c.gauss(c.gray(frames[idx]), 5, 1.5))
+                        assert np.array_equal(c.pipeline(frames[idx], 5, 1.5), chained)
+        except Exception as e:  # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
