@@ -690,3 +690,15 @@ def test_two_contexts_on_two_host_threads(pkg, oracle):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("h,w", [(130, 1024), (300, 500), (257, 252)])
+def test_sobel_commutes_with_flips_and_transposition(ctx, h, w):
+    """The Sobel magnitude of a mirrored / transposed frame is the mirrored / transposed magnitude (exact integer
+    arithmetic, symmetric stencil, reflect-101 borders) — which sends the same pixels through other strips, other
+    bands and the other walking direction of the kernels."""
+    img = rand_rgba(h, w, seed=h + w)
+    ref = ctx.sobel(img)
+    assert np.array_equal(ctx.sobel(np.ascontiguousarray(img[::-1])), ref[::-1])
+    assert np.array_equal(ctx.sobel(np.ascontiguousarray(img[:, ::-1])), ref[:, ::-1])
+    assert np.array_equal(ctx.sobel(np.ascontiguousarray(img.transpose(1, 0, 2))), ref.T)
