@@ -5,17 +5,28 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A "step" is one pass of the hot path (one batched kernel launch through the
-C-ABI, mi355_filter_dev) over this rank's batch of synthetic frames, which are generated on the GPU
-and resident in HBM before the timed region.  Frames shard by index (rank r owns frames
-[r*F, (r+1)*F)), no pixel ever crosses GPUs; the only collective on the data path's setup is one RCCL
-broadcast of the coefficient table from rank 0.  Weak scaling: F frames per GPU at every N.
+One process per GPU.  Started without a torch.distributed environment and with --gpus N > 1, this script spawns
+its N ranks itself (before anything touches a GPU) and exits with their worst exit code.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+A "step" is one pass of the hot path (one batched kernel launch through the C-ABI, mi355_filter_dev) over this
+rank's batch of synthetic frames, which are generated on the GPU and resident in HBM before the timed region.
+Frames shard by index, no pixel ever crosses GPUs; the only collective on the data path's setup is one RCCL
+broadcast of the coefficient table from rank 0.
+
+  default                     weak scaling: --frames F frames per GPU at every N (rank r owns [r*F, (r+1)*F))
+  --total-frames T            strong scaling: T frames in all, rank r owns [r*T/N, (r+1)*T/N)
+                              (BASELINE.json config 5: --filter pipeline --total-frames 512)
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  After the timed region rank 0
+copies four output frames back and compares them, whole, with the CPU restatement of the reference (oracle/,
+the checker — never on the measured path): the "parity" record; a violation of the stated tolerance makes the
+exit code 3.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,8 +43,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level
 ALGO_BPP = {"gauss": 8, "gray": 8, "gray1": 5, "sobel": 5, "pipeline": 5}
 FILTER_ID = {"gray": 0, "gray1": 1, "gauss": 2, "sobel": 3, "pipeline": 4}
 
+# Largest |GPU - oracle| a sampled output frame may show, per (filter, mode).  The FAST Gaussian is the
+# separable FMA form: <= 1 LSB per channel (BASELINE.json north_star); the FAST pipeline inherits that 1 LSB in
+# its blurred stage, which moves gx, gy by at most 4 each, the magnitude by at most 6.  Everything else is bit-exact.
+PARITY_TOL = {("gauss", "fast"): 1, ("gauss", "exact"): 0, ("gray", "fast"): 0, ("gray", "exact"): 0,
+              ("gray1", "fast"): 0, ("gray1", "exact"): 0, ("sobel", "fast"): 0, ("sobel", "exact"): 0,
+              ("pipeline", "fast"): 6, ("pipeline", "exact"): 0}
 
-def parse():
+
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     # defaults: 60 launches x ~3 ms.  The chip needs some tens of ms of continuous work to settle its clocks
@@ -46,6 +64,8 @@ def parse():
     p.add_argument("--frames", type=int, default=256, help="frames per GPU per step (>=32: working set must "
                    "exceed the 256 MiB Infinity Cache so the kernel streams from HBM; 256 x 4K = 8.5 GB in + "
                    "8.5 GB out of the 288 GB)")
+    p.add_argument("--total-frames", type=int, default=0, help="strong scaling: this many frames in all, split "
+                   "over the ranks in contiguous ranges (overrides --frames); 512 = BASELINE.json config 5")
     p.add_argument("--k", type=int, default=5)
     p.add_argument("--sigma", type=float, default=1.5)
     p.add_argument("--mode", default="fast", choices=["fast", "exact"])
@@ -55,19 +75,102 @@ def parse():
                    "general 4-channel path instead of its opaque fast path")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-ceiling", action="store_true", help="skip the device-copy ceiling measurement")
+    p.add_argument("--no-ceiling", action="store_true", help="skip the stream-copy ceiling measurement")
+    p.add_argument("--no-parity", action="store_true", help="skip the post-run oracle comparison of 4 frames")
+    p.add_argument("--no-side-figures", action="store_true", help="skip the general-alpha side measurement")
     p.add_argument("--pool-candidates", type=int, default=12,
                    help="output pools allocated and probed before the warm-up, the fastest is kept (1 = plain allocation)")
     p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
                    "many frames (>= --frames) but process only --frames of them")
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
+# ---- the multi-rank logic, kept in functions so tests/test_multi_rank.py runs THESE under gloo ---------------
+def shard_range(rank, world, frames_per_gpu, total_frames=0):
+    """(first_frame, nframes) of rank `rank`: contiguous frame ranges, nothing shared."""
+    if total_frames and total_frames > 0:
+        base, rem = divmod(int(total_frames), world)
+        return rank * base + min(rank, rem), base + (1 if rank < rem else 0)
+    return rank * int(frames_per_gpu), int(frames_per_gpu)
+
+
+def broadcast_table(dist, rank, k, make_table, device):
+    """The one data-path-setup collective: rank 0 generates the k x k coefficient table (make_table() -> float32
+    array), every rank receives the same bytes.  dist = torch.distributed module or None (single rank)."""
+    import torch
+    table = torch.zeros(k * k, dtype=torch.float32, device=device)
+    if rank == 0:
+        table.copy_(torch.from_numpy(np.ascontiguousarray(make_table(), np.float32).reshape(-1)))
+    if dist is not None:
+        dist.broadcast(table, src=0)
+    return table.cpu().numpy().reshape(k, k)
+
+
+def reduce_results(dist, elapsed, launch_ms, checksum, npixels, device):
+    """Max over ranks of the timed-region wall time and of the average launch time; sum over ranks of the pixels
+    processed per step and of the 64-bit checksums (mod 2^64, carried as two 32-bit halves in int64)."""
+    if dist is None:
+        return {"t_max": elapsed, "ms_max": launch_ms, "checksum": checksum & 0xFFFFFFFFFFFFFFFF, "pixels": int(npixels)}
+    import torch
+    t = torch.tensor([elapsed, launch_ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    c = torch.tensor([checksum & 0xFFFFFFFF, (checksum >> 32) & 0xFFFFFFFF, int(npixels)], dtype=torch.int64, device=device)
+    dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return {"t_max": float(t[0]), "ms_max": float(t[1]),
+            "checksum": (int(c[0]) + (int(c[1]) << 32)) & 0xFFFFFFFFFFFFFFFF, "pixels": int(c[2])}
+
+
+def checksum_index_base(first_frame, w, h, out_bpp):
+    """Word index of this rank's first output word in the whole job's output (checksums add up over ranks)."""
+    return first_frame * (w * h * out_bpp // 4)
+
+
+def sample_frame_ids(nframes, seed=0x5EED):
+    """First, last and two seeded-random local frame indices (SURVEY.md §8d "Parity sampling")."""
+    ids = {0, nframes - 1}
+    rng = np.random.default_rng(seed)
+    for _ in range(64):
+        if len(ids) >= min(4, nframes):
+            break
+        ids.add(int(rng.integers(0, nframes)))
+    return sorted(ids)
+
+
+def oracle_frame(oracle, name, frame, k, table, threads):
+    """The CPU restatement of the reference on one frame (the checker; oracle/)."""
+    if name == "gauss":
+        return oracle.gauss_rgba(frame, k, weights=table, threads=threads)
+    if name == "pipeline":
+        return oracle.pipeline_rgba(frame, k, weights=table)
+    return {"sobel": oracle.sobel_rgba, "gray": oracle.gray_rgba, "gray1": oracle.gray_rgba_1ch}[name](frame)
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a torch.distributed environment: start the N ranks as child processes.  The parent makes
+    no GPU call (it does not even import torch); a failing child makes the exit code non-zero."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rcs = [p.wait() for p in procs]
+    return max((abs(rc) for rc in rcs), default=0)
+
+
+# ---- CPU baseline -------------------------------------------------------------------------------------------
 def cpu_baseline(args, oracle):
     """The reference's CPU path (our C restatement, oracle/), timed on this box's host cores on a
     bounded sample of the same workload.  Test/measurement infrastructure: never on the product path."""
-    if args.filter not in ("gauss", "pipeline", "sobel", "gray", "gray1"):
-        return None
     w, h = args.width, args.height
     fn = {
         "gauss": lambda f, t: oracle.gauss_rgba(f, args.k, args.sigma, threads=t),
@@ -103,16 +206,18 @@ def cpu_baseline(args, oracle):
     return out
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, argv))
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
@@ -131,35 +236,46 @@ def main():
     ctx = pkg.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_gauss_mode(pkg.GAUSS_EXACT if args.mode == "exact" else pkg.GAUSS_FAST)
 
-    w, h, F = args.width, args.height, args.frames
+    w, h = args.width, args.height
+    first_frame, F = shard_range(rank, world, args.frames, args.total_frames)
+    if F <= 0:
+        raise SystemExit("rank %d has no frames (--total-frames %d over %d ranks)" % (rank, args.total_frames, world))
     filt = FILTER_ID[args.filter]
     out_bpp = pkg.imgfilter.OUT_BPP[filt]
     FA = max(F, args.alloc_frames)
     d_in = torch.empty((FA, h, w, 4), dtype=torch.uint8, device=dev)[:F]
-    first_frame = rank * F
     ctx.synth_dev(d_in.data_ptr(), w, h, F, first_frame=first_frame, seed=0x5EED, mode=args.synth_mode)
     if args.random_alpha:
         d_in[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
+
+    # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes
+    table = None
+    if args.filter in ("gauss", "pipeline"):
+        table = broadcast_table(dist, rank, args.k, lambda: pkg.gauss_weights(args.k, args.sigma), dev)
+        ctx.set_gauss_weights(args.k, args.sigma, table)
+
+    def launch(src, dst, n=F):
+        ctx.filter_dev(filt, src, dst, w, h, n, args.k, args.sigma)
 
     # Pool placement: where the two frame pools land physically decides up to 8 % of the
     # streaming rate on this chip, and an allocation cannot be steered, only re-drawn.  So several candidate output
     # pools are allocated side by side (all alive at once, hence all in different places), each is probed with a
     # handful of launches of the very filter to be measured, the fastest is kept and the others are freed.
-    # This is set-up: it happens before the warm-up, outside the timed region, and its probes are reported.
+    # This is set-up: it happens before the warm-up, outside the timed region, and its probes are reported
+    # (the first candidate IS the plain allocation: roofline.frac_plain_alloc).
     def probe(out_t, launches=8):
         for _ in range(4):
-            ctx.filter_dev(filt, d_in.data_ptr(), out_t.data_ptr(), w, h, F, args.k, args.sigma)
+            launch(d_in.data_ptr(), out_t.data_ptr())
         torch.cuda.synchronize(dev)
         ctx.timer_begin()
         for _ in range(launches):
-            ctx.filter_dev(filt, d_in.data_ptr(), out_t.data_ptr(), w, h, F, args.k, args.sigma)
+            launch(d_in.data_ptr(), out_t.data_ptr())
         return ctx.timer_end() / launches
 
     pool_probes = []
     out_bytes = FA * h * w * out_bpp
     free_b, _total = torch.cuda.mem_get_info(dev)
     ncand = max(1, min(args.pool_candidates, int((free_b - (24 << 30)) // max(out_bytes, 1))))
-    # candidates are added one at a time and stay allocated while the search runs
     cands = []
     for _ in range(ncand):
         cands.append(torch.empty((FA, h, w, out_bpp), dtype=torch.uint8, device=dev))
@@ -167,7 +283,7 @@ def main():
             break
         if not pool_probes:              # clocks up before the first probe, or it reads slow for the wrong reason
             for _ in range(20):
-                ctx.filter_dev(filt, d_in.data_ptr(), cands[0].data_ptr(), w, h, F, args.k, args.sigma)
+                launch(d_in.data_ptr(), cands[0].data_ptr())
         pool_probes.append(round(probe(cands[-1]), 4))
         # there are more than two states (gray on one box: 6.08 / 6.31 / 6.72 / 6.79 TB/s over six pools), so the
         # search only stops early when it has seen enough pools AND holds one clearly out of the slow state
@@ -179,17 +295,8 @@ def main():
     torch.cuda.empty_cache()
     d_out = d_out_full[:F]
 
-    # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes
-    if args.filter in ("gauss", "pipeline"):
-        table = torch.zeros(args.k * args.k, dtype=torch.float32, device=dev)
-        if rank == 0:
-            table.copy_(torch.from_numpy(pkg.gauss_weights(args.k, args.sigma).reshape(-1)))
-        if dist is not None:
-            dist.broadcast(table, src=0)
-        ctx.set_gauss_weights(args.k, args.sigma, table.cpu().numpy())
-
     def step():
-        ctx.filter_dev(filt, d_in.data_ptr(), d_out.data_ptr(), w, h, F, args.k, args.sigma)
+        launch(d_in.data_ptr(), d_out.data_ptr())
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -197,21 +304,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # on-box streaming ceiling for the same byte count: a device-to-device copy of the input batch
-    # (reads 4 B/px, writes 4 B/px = the Gaussian's algorithmic traffic), timed with the same events
+    # On-box streaming ceiling for the Gaussian's byte count: the library's own non-temporal 16 B/lane copy kernel
+    # (mi355_stream_copy_dev) moving the input batch into the output pool: reads 4 B/px, writes 4 B/px.
     copy_gbs = None
-    if rank == 0 and not args.no_ceiling:
-        scratch = torch.empty_like(d_in)
-        for _ in range(2):
-            scratch.copy_(d_in)
+    if rank == 0 and not args.no_ceiling and out_bpp == 4:
+        nb = d_in.numel()
+        for _ in range(3):
+            ctx.stream_copy_dev(d_out.data_ptr(), d_in.data_ptr(), nb)
         torch.cuda.synchronize(dev)
         ctx.timer_begin()
-        for _ in range(5):
-            scratch.copy_(d_in)
-        copy_ms = ctx.timer_end() / 5
-        copy_gbs = 2 * d_in.numel() / (copy_ms * 1e-3) / 1e9
-        del scratch
-        torch.cuda.empty_cache()
+        for _ in range(8):
+            ctx.stream_copy_dev(d_out.data_ptr(), d_in.data_ptr(), nb)
+        copy_ms = ctx.timer_end() / 8
+        copy_gbs = 2 * nb / (copy_ms * 1e-3) / 1e9
 
     for _ in range(args.warmup):
         step()
@@ -226,24 +331,17 @@ def main():
 
     # one launch per step: average launch duration from the HIP events around the timed region
     avg_launch_ms = kernel_ms / args.steps
-    checksum = ctx.checksum_dev(d_out.data_ptr(), d_out.numel(), index_base=first_frame * (w * h * out_bpp // 4))
+    checksum = ctx.checksum_dev(d_out.data_ptr(), d_out.numel(),
+                                index_base=checksum_index_base(first_frame, w, h, out_bpp))
+    red = reduce_results(dist, elapsed, avg_launch_ms, checksum, F * w * h, dev)
 
-    t_max, ms_max, ck_sum = elapsed, avg_launch_ms, checksum
-    if dist is not None:
-        t = torch.tensor([elapsed, avg_launch_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        t_max, ms_max = float(t[0]), float(t[1])
-        # 64-bit modular sum of per-rank checksums, carried as two 32-bit halves in int64
-        c = torch.tensor([checksum & 0xFFFFFFFF, checksum >> 32], dtype=torch.int64, device=dev)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        ck_sum = (int(c[0]) + (int(c[1]) << 32)) & 0xFFFFFFFFFFFFFFFF
-
+    rc = 0
     if rank == 0:
         px_per_launch = F * w * h
-        total_px = world * px_per_launch * args.steps
+        total_px = red["pixels"] * args.steps
         algo_bytes = ALGO_BPP[args.filter] * px_per_launch
         achieved = algo_bytes / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
@@ -251,45 +349,109 @@ def main():
                 key = "%s_%dx%d_f%d_k%d" % (args.filter, w, h, F, args.k)
                 if key in pmc:
                     traffic = pmc[key]["hbm_bytes_per_launch"]
+                    traffic_src = ("OFFLINE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                   "(tools/prof.sh), committed in profiles/pmc_traffic.json[%s]; not measured in this run" % key)
             except Exception:
                 traffic = None
+        strong = bool(args.total_frames)
+        headline = (args.filter, args.k, w, h) == ("gauss", 5, 3840, 2160)
         line = {
-            "metric": "Mpixels/s (Gaussian 5x5, 4K RGBA)" if (args.filter, args.k, w, h) == ("gauss", 5, 3840, 2160)
+            "metric": "Mpixels/s (Gaussian 5x5, 4K RGBA)" if headline
                       else "Mpixels/s (%s k=%d, %dx%d RGBA)" % (args.filter, args.k, w, h),
-            "value": total_px / t_max / 1e6,
+            "value": total_px / red["t_max"] / 1e6,
             "unit": "Mpixels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": t_max / args.steps * 1e3,
+            "ms_per_step": red["t_max"] / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u8 in/out, f32 accumulate" if args.filter in ("gauss", "pipeline") else "u8 in/out, f64 luminance",
             "data": "synthetic (device-generated counter-hash frames, resident in HBM before timing)",
-            "config": {"workload": "%s k=%d sigma=%g, %dx%d RGBA, %d frames/GPU/step, mode=%s" %
-                                   (args.filter, args.k, args.sigma, w, h, F, args.mode),
-                       "frames_per_gpu": F, "width": w, "height": h, "parallelism": "frames sharded x%d" % world,
-                       "alpha": "random" if args.random_alpha else "255 (opaque frames, as after cvtColor BGR2RGBA)"},
+            "config": {"workload": "%s k=%d sigma=%g, %dx%d RGBA, %s, mode=%s" %
+                                   (args.filter, args.k, args.sigma, w, h,
+                                    ("%d frames in all" % args.total_frames) if strong else ("%d frames/GPU/step" % F),
+                                    args.mode),
+                       "frames_per_gpu": F, "total_frames": red["pixels"] // (w * h), "width": w, "height": h,
+                       "parallelism": "frames sharded x%d" % world,
+                       "alpha": "random" if args.random_alpha else "255 (opaque frames, as after cvtColor BGR2RGBA)",
+                       "tolerance_vs_cpu_path": "max |diff| <= %d per output byte" % PARITY_TOL[(args.filter, args.mode)]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          # the north star words the target as "HBM-read roofline": the 4 B/px input stream alone
                          "achieved_read_only_GBs": 4 * px_per_launch / (avg_launch_ms * 1e-3) / 1e9,
-                         "copy_ceiling_GBs": copy_gbs,
-                         "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                         "avg_launch_ms": avg_launch_ms, "avg_launch_ms_max_over_ranks": ms_max,
+                         "avg_launch_ms": avg_launch_ms, "avg_launch_ms_max_over_ranks": red["ms_max"],
                          "kernel": "see profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
-            "checksum": "%016x" % ck_sum,
+            "checksum": "%016x" % red["checksum"],
             "pool_placement": pool_probes,
         }
+        if pool_probes:
+            # the first candidate is what a plain allocation gives; the kept one is the searched placement
+            line["roofline"]["frac_plain_alloc"] = algo_bytes / (pool_probes[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            line["roofline"]["frac_searched_probe"] = algo_bytes / (min(pool_probes) * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if copy_gbs:
+            line["roofline"]["copy_ceiling_GBs"] = copy_gbs
+            line["roofline"]["copy_ceiling_kernel"] = "mi355_stream_copy_dev (nt 16 B/lane), same two buffers"
+            if ALGO_BPP[args.filter] == 8:
+                line["roofline"]["frac_of_copy_ceiling"] = achieved / copy_gbs
+
+        # ---- side figure: the Gaussian's general 4-channel path (non-opaque frames), same run, same pools -----
+        if args.filter == "gauss" and not args.random_alpha and not args.no_side_figures and args.mode == "fast":
+            d_in2 = d_in.clone()
+            d_in2[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
+            for _ in range(4):
+                launch(d_in2.data_ptr(), d_out.data_ptr())
+            torch.cuda.synchronize(dev)
+            ctx.timer_begin()
+            for _ in range(12):
+                launch(d_in2.data_ptr(), d_out.data_ptr())
+            ms2 = ctx.timer_end() / 12
+            line["general_path"] = {"what": "same launch on frames with random alpha (no opaque fast path), 12 launches",
+                                    "avg_launch_ms": ms2, "achieved": algo_bytes / (ms2 * 1e-3) / 1e9,
+                                    "frac": algo_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del d_in2
+            torch.cuda.empty_cache()
+            step()  # d_out holds the opaque frames' result again for the parity sample below
+            torch.cuda.synchronize(dev)
+
+        # ---- checker leg (oracle/): parity sample, then the CPU baseline --------------------------------------
+        oracle = None
+        if not args.no_parity or (world == 1 and not args.no_cpu_baseline):
+            oracle = entry.load_oracle()
+        if not args.no_parity:
+            tol = PARITY_TOL[(args.filter, args.mode)]
+            ids = sample_frame_ids(F)
+            threads = max(1, min(oracle.max_threads(), 32))
+            worst, nbad, nval = 0, 0, 0
+            fin = np.empty((h, w, 4), np.uint8)
+            fout = np.empty((h, w, out_bpp) if out_bpp == 4 else (h, w), np.uint8)
+            for f in ids:
+                ctx.d2h(fin, d_in.data_ptr() + f * h * w * 4)
+                ctx.d2h(fout, d_out.data_ptr() + f * h * w * out_bpp)
+                ref = oracle_frame(oracle, args.filter, fin, args.k, table, threads)
+                d = np.abs(fout.astype(np.int16) - ref.reshape(fout.shape).astype(np.int16))
+                worst = max(worst, int(d.max()))
+                nbad += int((d != 0).sum())
+                nval += d.size
+            ok = worst <= tol
+            line["parity"] = {"frames": len(ids), "frame_ids": [first_frame + f for f in ids], "max_abs_diff": worst,
+                              "mismatch_frac": nbad / max(nval, 1), "tolerance": tol, "ok": ok,
+                              "against": "oracle/ (C restatement of the reference CPU path), whole frames, "
+                                         "inputs copied back from the device"}
+            if not ok:
+                rc = 3
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, entry.load_oracle())
+            line["cpu_baseline"] = cpu_baseline(args, oracle)
         print(json.dumps(line), flush=True)
 
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -97,7 +97,11 @@ int mi355_bgr_to_rgba8_dev(mi355_ctx* ctx, const void* d_bgr, void* d_rgba, int 
  *
  * mi355_ctx_set_gauss_weights installs an externally supplied k*k table (multi-GPU mode: rank 0
  * generates it, RCCL broadcasts it, every rank installs the same bytes) for the given (k, sigma)
- * key; later calls with that (k, sigma) use it instead of regenerating. */
+ * key; later calls with that (k, sigma) use it instead of regenerating.  The table is applied as given: when it
+ * is not w (x) w for one non-negative vector w up to float rounding (a non-separable or asymmetric table, negative
+ * lobes), the separable FAST kernels do not apply and every call with that key runs the tap-by-tap (EXACT
+ * arithmetic) kernel, as the reference kernel would (RT/kernel/gaussian_base.cl:23-44).  Non-finite entries are
+ * rejected (MI355_ERR_BAD_ARG).  A context keeps the 16 most recently used tables. */
 int mi355_gauss_weights(int k, float sigma, float* out_k2);
 int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, const float* w_k2);
 
@@ -162,6 +166,8 @@ int mi355_host_free(mi355_ctx* ctx, void* h_ptr);
 /* ---- device-resident calls -----------------------------------------------------------------
  * d_in / d_out are device pointers on the context's GPU holding nframes tightly packed frames;
  * the call enqueues the kernel(s) on the context's stream and returns without synchronising.
+ * [d_in, d_in + 4*w*h*nframes) and the output range must not overlap: every kernel reads neighbouring rows and
+ * halo pixels, so an in-place call is rejected with MI355_ERR_BAD_ARG instead of returning corrupted pixels.
  * These are what a caller that already owns device memory (torch, a capture pipeline) binds, and
  * what the roofline measurement times (no PCIe in the timed region). */
 int mi355_gray_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
@@ -183,6 +189,12 @@ int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes
  * batch over GPUs and adding the per-rank values gives the single-GPU value. */
 int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbytes, uint64_t index_base,
                        uint64_t* out);
+
+/* Streaming device-to-device copy of nbytes (non-overlapping) on the context's stream, no synchronisation: 16 B per
+ * lane, non-temporal loads and stores.  A measurement helper: bench.py times it on the same buffers as the filter
+ * to report the box's own "read N + write N bytes" ceiling beside the 8 TB/s spec peak (hipMemcpy D2D is ~25 %
+ * slower than this form on MI355X and is not a ceiling).  Replaces nothing in the reference. */
+int mi355_stream_copy_dev(mi355_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes);
 
 /* Device self-test of the two fast arithmetic forms the kernels use in place of the reference's FP64 luminance
  * (src/Grayscale/grayscale.cpp:237) and sqrt + round + saturate (src/EdgeDetection/EdgeDetection.cpp:236-240):

@@ -23,7 +23,10 @@ struct CoefEntry {
     uint32_t sigma_bits;
     GaussCoef coef;
     float* d_buf;  // [k*k w2d][k w1d]
+    uint64_t last_use;
 };
+
+constexpr size_t kMaxCoefEntries = 16;  // distinct (k, sigma) tables kept per context; least recently used goes
 
 }  // namespace
 
@@ -57,6 +60,7 @@ struct mi355_ctx {
     int last_hip = 0;
     char name[256] = {};
     std::vector<CoefEntry> coefs;
+    uint64_t coef_clock = 0;
     std::vector<void*> pinned;  // mi355_host_alloc blocks still outstanding (freed at destroy)
 };
 
@@ -107,19 +111,38 @@ void gen_weights(int k, float sigma, float* out)
         out[i] /= sum;
 }
 
-// separable factor of the table for the FAST arithmetic: rowsum / sqrt(total), in double
-void separable_factor(int k, const float* w2d, float* w1d)
+// Separable factor of the table for the FAST arithmetic: rowsum / sqrt(total), in double.  Returns whether the
+// factor really reproduces the table: every entry non-negative, total > 0 and |w2d[i][j] - w1d[i] * w1d[j]| within
+// float rounding of the largest entry (the reference's own tables deviate by <= 1.8e-7 of it for every odd k <= 63;
+// the bound used is 1e-6).  A table that fails — non-separable, asymmetric, negative lobes — must not go through
+// the separable kernels: the caller routes it to the tap-by-tap tiled kernel.
+bool separable_factor(int k, const float* w2d, float* w1d)
 {
-    double tot = 0.0;
+    double tot = 0.0, wmax = 0.0;
+    bool nonneg = true;
     std::vector<double> rs(k, 0.0);
     for (int i = 0; i < k; i++) {
-        for (int j = 0; j < k; j++)
-            rs[i] += (double)w2d[i * k + j];
+        for (int j = 0; j < k; j++) {
+            const double v = (double)w2d[i * k + j];
+            rs[i] += v;
+            nonneg = nonneg && v >= 0.0;
+            wmax = std::fmax(wmax, std::fabs(v));
+        }
         tot += rs[i];
+    }
+    if (!nonneg || !(tot > 0.0)) {
+        for (int i = 0; i < k; i++)
+            w1d[i] = 0.0f;
+        return false;
     }
     const double s = std::sqrt(tot);
     for (int i = 0; i < k; i++)
         w1d[i] = (float)(rs[i] / s);
+    double dev = 0.0;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++)
+            dev = std::fmax(dev, std::fabs((double)w2d[i * k + j] - (double)w1d[i] * (double)w1d[j]));
+    return dev <= 1.0e-6 * wmax;
 }
 
 int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const GaussCoef** out)
@@ -129,6 +152,16 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
         if (e.k == k && e.sigma_bits == fbits(sigma))
             slot = &e;
     if (!slot) {
+        if (ctx->coefs.size() >= kMaxCoefEntries) {
+            // evict the least recently used table; a kernel still in flight may be reading it
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            size_t lru = 0;
+            for (size_t i = 1; i < ctx->coefs.size(); i++)
+                if (ctx->coefs[i].last_use < ctx->coefs[lru].last_use)
+                    lru = i;
+            (void)hipFree(ctx->coefs[lru].d_buf);
+            ctx->coefs.erase(ctx->coefs.begin() + (long)lru);
+        }
         CoefEntry e{};
         e.k = k;
         e.sigma_bits = fbits(sigma);
@@ -136,9 +169,10 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
         ctx->coefs.push_back(e);
         slot = &ctx->coefs.back();
     }
+    slot->last_use = ++ctx->coef_clock;
     std::vector<float> host((size_t)k * k + k);
     std::memcpy(host.data(), w2d, sizeof(float) * (size_t)k * k);
-    separable_factor(k, w2d, host.data() + (size_t)k * k);
+    const bool separable = separable_factor(k, w2d, host.data() + (size_t)k * k);
     // blocking copy from pageable memory: the table is live on the device when this returns
     const hipError_t ce = hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice);
     if (ce != hipSuccess) {
@@ -149,6 +183,7 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
         return MI355_ERR_HIP;
     }
     slot->coef.k = k;
+    slot->coef.separable = separable;
     slot->coef.d_w2d = slot->d_buf;
     slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
     std::memset(slot->coef.h_w1d, 0, sizeof(slot->coef.h_w1d));
@@ -162,6 +197,7 @@ int get_coef(mi355_ctx* ctx, int k, float sigma, const GaussCoef** out)
 {
     for (auto& e : ctx->coefs)
         if (e.k == k && e.sigma_bits == fbits(sigma)) {
+            e.last_use = ++ctx->coef_clock;
             *out = &e.coef;
             return MI355_OK;
         }
@@ -222,6 +258,19 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
     const bool rgba_out = (filter == MI355_FILTER_GRAY || filter == MI355_FILTER_GAUSS);
     if (rgba_out && (reinterpret_cast<uintptr_t>(d_out) & 3u))
         return MI355_ERR_BAD_ARG;
+    {
+        // every kernel reads neighbouring rows / halo pixels of what another wave may already have overwritten:
+        // in-place and overlapping calls are rejected, not run (the reference never aliases them either: two
+        // clCreateBuffer objects per call, RT/src/Controller.cpp:234-244)
+        const int bpp = mi355_filter_out_bpp(filter);
+        if (bpp < 0)
+            return MI355_ERR_BAD_ARG;
+        const size_t npx = (size_t)w * h * nframes;
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_in), a1 = a0 + npx * 4;
+        const uintptr_t b0 = reinterpret_cast<uintptr_t>(d_out), b1 = b0 + npx * (size_t)bpp;
+        if (a0 < b1 && b0 < a1)
+            return MI355_ERR_BAD_ARG;
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const GaussCoef* coef = nullptr;
     if (filter_needs_gauss(filter)) {
@@ -233,7 +282,8 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
     }
     const uint8_t* in = static_cast<const uint8_t*>(d_in);
     uint8_t* out = static_cast<uint8_t*>(d_out);
-    const bool exact = ctx->gauss_mode == MI355_GAUSS_EXACT;
+    // a table the separable factor does not reproduce is applied tap by tap, whatever the mode
+    const bool exact = ctx->gauss_mode == MI355_GAUSS_EXACT || (coef && !coef->separable);
     hipError_t e;
     switch (filter) {
     case MI355_FILTER_GRAY:
@@ -461,6 +511,7 @@ MI355_API int mi355_sync(mi355_ctx* ctx)
 {
     if (!ctx)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI355_OK;
 }
@@ -531,6 +582,9 @@ MI355_API int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, co
 {
     if (!ctx || !w_k2 || !valid_k(k) || !valid_sigma(sigma))
         return MI355_ERR_BAD_ARG;
+    for (int i = 0; i < k * k; i++)
+        if (!std::isfinite(w_k2[i]))
+            return MI355_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // a kernel still in flight may be reading the previous table of this key
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -775,6 +829,7 @@ MI355_API int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, i
         return rc;
     if (reinterpret_cast<uintptr_t>(d_out) & 3u)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, launch_synth(ctx->stream, static_cast<uint8_t*>(d_out), w, h, nframes, first_frame, seed,
                               mode));
     return MI355_OK;
@@ -785,6 +840,7 @@ MI355_API int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbyte
 {
     if (!ctx || !d_buf || !out)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_checksum(ctx->stream, static_cast<const uint8_t*>(d_buf), nbytes, index_base,
                                  ctx->d_acc));
@@ -795,10 +851,24 @@ MI355_API int mi355_checksum_dev(mi355_ctx* ctx, const void* d_buf, size_t nbyte
     return MI355_OK;
 }
 
+MI355_API int mi355_stream_copy_dev(mi355_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes)
+{
+    if (!ctx || !d_dst || !d_src)
+        return MI355_ERR_BAD_ARG;
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(d_src), b0 = reinterpret_cast<uintptr_t>(d_dst);
+    if (a0 < b0 + nbytes && b0 < a0 + nbytes)
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, launch_stream_copy(ctx->stream, static_cast<const uint8_t*>(d_src), static_cast<uint8_t*>(d_dst),
+                                    nbytes));
+    return MI355_OK;
+}
+
 MI355_API int mi355_selftest(mi355_ctx* ctx, uint32_t* bad_luma, uint32_t* bad_mag)
 {
     if (!ctx || !bad_luma || !bad_mag)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_acc, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(ctx, launch_selftest(ctx->stream, ctx->d_acc));
     unsigned long long v = 0;
@@ -913,6 +983,7 @@ MI355_API int mi355_pool_free(mi355_ctx* ctx, void* d_in, void* d_out)
 {
     if (!ctx)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (d_in)
         HIP_TRY(ctx, hipFree(d_in));
@@ -927,6 +998,7 @@ MI355_API int mi355_dev_free(mi355_ctx* ctx, void* d_ptr)
         return MI355_ERR_BAD_ARG;
     if (!d_ptr)
         return MI355_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipFree(d_ptr));
     return MI355_OK;
@@ -936,6 +1008,7 @@ MI355_API int mi355_copy_h2d(mi355_ctx* ctx, void* d_dst, const void* h_src, siz
 {
     if (!ctx || !d_dst || !h_src)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI355_OK;
@@ -945,6 +1018,7 @@ MI355_API int mi355_copy_d2h(mi355_ctx* ctx, void* h_dst, const void* d_src, siz
 {
     if (!ctx || !h_dst || !d_src)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MI355_OK;
@@ -954,6 +1028,7 @@ MI355_API int mi355_timer_begin(mi355_ctx* ctx)
 {
     if (!ctx)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->t0, ctx->stream));
     return MI355_OK;
 }
@@ -962,6 +1037,7 @@ MI355_API int mi355_timer_end(mi355_ctx* ctx, float* elapsed_ms)
 {
     if (!ctx || !elapsed_ms)
         return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventRecord(ctx->t1, ctx->stream));
     HIP_TRY(ctx, hipEventSynchronize(ctx->t1));
     HIP_TRY(ctx, hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));

@@ -11,9 +11,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+
 namespace mi355 {
 
 constexpr int kWave = 64;
+
+// MI355_TUNE_* environment overrides (band heights, strip widths, kernel selection) exist for tuning sweeps
+// and for the test that proves outputs do not depend on the work decomposition.  They are compiled in only
+// with -DMI355_TUNE_ENV (lib/libmi355_imgfilter_tune.so, `make tune`); the product library reads no environment.
+inline const char* tune_env(const char* name)
+{
+#ifdef MI355_TUNE_ENV
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // 16-byte vector of four RGBA pixels (one dword each): the unit of every coalesced access
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;

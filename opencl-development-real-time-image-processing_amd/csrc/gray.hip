@@ -165,15 +165,15 @@ hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, 
     // grid-stride; measured on MI355X (tools/membench.hip): a flat 16 B/lane stream runs 5.3 TB/s with
     // 2,048 blocks, 6.2-6.4 TB/s with >= 8k blocks and non-temporal loads + stores; this kernel: 4.8 / 5.6 / 5.9 / 6.3 TB/s at 2k / 8k / 64k / 256k+ blocks
     static const unsigned kCap = [] {
-        const char* e = getenv("MI355_TUNE_GRAY_BLOCKS");  // tuning sweeps only
+        const char* e = tune_env("MI355_TUNE_GRAY_BLOCKS");  // tuning sweeps only
         return (e && atoi(e) > 0) ? (unsigned)atoi(e) : (1u << 20);
     }();
     // Rows of 4-pixel multiples take the strip-walk kernel with 4-row bands: measured on 256 x 4K frames, same
     // box, flat kernel 6.36 TB/s, strips of 4 / 8 / 16 / 32 rows 6.61 / 6.49 / 6.39 / 6.27 (1-channel output: 6.08
     // flat, 6.33 with 4 rows).  MI355_TUNE_GRAY_STRIP (tuning sweeps only): band height, 0 = flat kernel.
-    static const bool kStripForced = getenv("MI355_TUNE_GRAY_STRIP") != nullptr;  // tests: also on small shapes
+    static const bool kStripForced = tune_env("MI355_TUNE_GRAY_STRIP") != nullptr;  // tests: also on small shapes
     static const int kStripRows = [] {
-        const char* e = getenv("MI355_TUNE_GRAY_STRIP");
+        const char* e = tune_env("MI355_TUNE_GRAY_STRIP");
         return e ? atoi(e) : 4;
     }();
     // ... and only where it pays: big batches (8 x 4K frames: -2.5 %, 256: +2 %) of rows that fill the 64-lane

@@ -15,6 +15,10 @@ struct GaussCoef {
     const float* d_w2d;
     const float* d_w1d;
     float h_w1d[64];  // host copy, passed by value to the register-resident kernels
+    // true when w2d == w1d (x) w1d up to float rounding, with non-negative entries: the FAST (separable) kernels
+    // may stand in for the 2-D table.  Externally installed tables that are not (mi355_ctx_set_gauss_weights) are
+    // applied tap by tap by the tiled kernels, as the reference kernel applies them (RT/kernel/gaussian_base.cl:23-44).
+    bool separable;
 };
 
 hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
@@ -61,6 +65,9 @@ hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nf
 
 // packed BGR (3 B/px) -> RGBA (A = 255), cv::cvtColor(BGR2RGBA)
 hipError_t launch_bgr_to_rgba(hipStream_t stream, const uint8_t* d_bgr, uint8_t* d_rgba, size_t npx);
+
+// streaming device-to-device copy (non-temporal, 16 B/lane): the on-box "read N + write N bytes" ceiling
+hipError_t launch_stream_copy(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, size_t nbytes);
 
 // *d_acc += order-independent checksum of nbytes at d_buf (see include/mi355_imgfilter.h)
 hipError_t launch_selftest(hipStream_t stream, unsigned long long* d_acc);

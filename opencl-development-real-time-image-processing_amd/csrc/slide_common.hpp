@@ -47,7 +47,7 @@ inline StripPlan make_strip_plan(int w, int lanes_pref = 0)
         s.nstrips = (s.quads + lanes_pref - 1) / lanes_pref;
     }
     static const int tune_lanes = [] {  // MI355_TUNE_LANES_OUT: tuning sweeps only
-        const char* e = getenv("MI355_TUNE_LANES_OUT");
+        const char* e = tune_env("MI355_TUNE_LANES_OUT");
         return e ? atoi(e) : 0;
     }();
     if (tune_lanes > 0 && tune_lanes <= kSlideLanesOutMax) {
@@ -74,11 +74,11 @@ inline bool make_band_plan(int h, int nstrips, int nframes, int waves_per_simd, 
         double tail_frac = -1.0;
         Tune()
         {
-            if (const char* e = getenv("MI355_TUNE_BAND_ROWS"))
+            if (const char* e = tune_env("MI355_TUNE_BAND_ROWS"))
                 band_rows = atoi(e);
-            if (const char* e = getenv("MI355_TUNE_TAIL_ROWS"))
+            if (const char* e = tune_env("MI355_TUNE_TAIL_ROWS"))
                 tail_rows = atoi(e);
-            if (const char* e = getenv("MI355_TUNE_TAIL_FRAC"))
+            if (const char* e = tune_env("MI355_TUNE_TAIL_FRAC"))
                 tail_frac = atof(e);
         }
     } tune;

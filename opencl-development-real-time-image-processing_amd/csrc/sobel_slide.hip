@@ -296,7 +296,7 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
 {
     static const int kStripMode = [] {
         // tuning sweeps and tests only: 0 = never use the aligned-strip kernel, 2 = whenever the rows allow it
-        const char* e = getenv("MI355_TUNE_SOBEL_STRIP");
+        const char* e = tune_env("MI355_TUNE_SOBEL_STRIP");
         return e ? atoi(e) : 1;
     }();
     const bool kStripOff = kStripMode == 0;

@@ -133,6 +133,35 @@ __global__ __launch_bounds__(kThreads) void selftest_kernel(unsigned long long* 
         atomicAdd(acc, (unsigned long long)bad_luma | ((unsigned long long)bad_mag << 32));
 }
 
+// Streaming copy, 16 B per lane, non-temporal loads and stores, 4 accesses in flight per lane: the on-box
+// ceiling for "read N bytes + write N bytes" that bench.py reports beside the filter kernels (tools/membench.hip
+// measured this form at 6.2-6.4 TB/s with >= 8k blocks; hipMemcpy D2D reaches only 4.4-4.7).
+__global__ __launch_bounds__(kThreads) void stream_copy_kernel(const u32x4* __restrict__ in, u32x4* __restrict__ out,
+                                                               size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            v[u] = __builtin_nontemporal_load(&in[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            __builtin_nontemporal_store(v[u], &out[i + u * stride]);
+    }
+    for (; i < n; i += stride)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(&in[i]), &out[i]);
+}
+
+__global__ __launch_bounds__(kThreads) void byte_copy_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                             size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n)
+        out[i] = in[i];
+}
+
 }  // namespace
 
 hipError_t launch_selftest(hipStream_t stream, unsigned long long* d_acc)
@@ -165,6 +194,30 @@ hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nf
         blocks = 1;
     hipLaunchKernelGGL(synth_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream,
                        reinterpret_cast<uint32_t*>(d_out), w, h, nframes, first_frame, seed, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_stream_copy(hipStream_t stream, const uint8_t* d_src, uint8_t* d_dst, size_t nbytes)
+{
+    if (nbytes == 0)
+        return hipSuccess;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 15u) == 0;
+    const size_t nvec = aligned ? nbytes / 16 : 0;
+    if (nvec) {
+        size_t blocks = (nvec + (size_t)kThreads * 4 - 1) / ((size_t)kThreads * 4);
+        if (blocks > (1u << 16))
+            blocks = 1u << 16;
+        hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                           reinterpret_cast<const u32x4*>(d_src), reinterpret_cast<u32x4*>(d_dst), nvec);
+    }
+    const size_t done = nvec * 16, rest = nbytes - done;
+    if (rest) {
+        const size_t blocks = (rest + kThreads - 1) / kThreads;
+        if (blocks > 0x7FFFFFFFull)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(byte_copy_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, d_src + done,
+                           d_dst + done, rest);
+    }
     return hipGetLastError();
 }
 

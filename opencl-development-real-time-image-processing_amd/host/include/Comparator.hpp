@@ -25,6 +25,10 @@ public:
 private:
     int m_num_methods;
     int NUMBER_OF_ITERATIONS;
+
+    // include/Comparator.hpp:21 of the reference (mean absolute difference of two images); declaration only,
+    // like the rest of this class
+    double ComputeMAE(const cv::Mat& reference, const cv::Mat& result, Logger& logger);
 };
 
 #endif  // COMPARATOR_H

@@ -44,7 +44,7 @@ def library_path():
 
 def build_library(jobs=8):
     """Compile csrc/*.hip for gfx950 into lib/libmi355_imgfilter.so (hipcc cross-compiles without a GPU)."""
-    subprocess.run(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc")], check=True)
+    subprocess.run(["make", "-s", "-j%d" % jobs, "-C", os.path.join(_HERE, "csrc"), "all", "tune"], check=True)
     return _LIB
 
 
@@ -100,6 +100,7 @@ def load_library():
         "mi355_filter_dev": [_vp, _ci, _vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_float],
         "mi355_synth_rgba8_dev": [_vp, _vp, _ci, _ci, _ci, _ci, ctypes.c_uint32, _ci],
         "mi355_checksum_dev": [_vp, _vp, ctypes.c_size_t, ctypes.c_uint64, _u64p],
+        "mi355_stream_copy_dev": [_vp, _vp, _vp, ctypes.c_size_t],
         "mi355_selftest": [_vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)],
         "mi355_dev_alloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
         "mi355_pool_alloc": [_vp, _ci, _ci, _ci, _ci, _ci, ctypes.c_float, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
@@ -310,6 +311,10 @@ class Context:
                                           ctypes.byref(out))
         _check("mi355_checksum_dev", rc, self._h)
         return out.value
+
+    def stream_copy_dev(self, d_dst, d_src, nbytes):
+        rc = self._lib.mi355_stream_copy_dev(self._h, _vp(int(d_dst)), _vp(int(d_src)), int(nbytes))
+        _check("mi355_stream_copy_dev", rc, self._h)
 
     def selftest(self):
         """(bad_luma, bad_mag): exhaustive on-device check of the fast luminance / magnitude forms; (0, 0) = good."""

@@ -9,7 +9,7 @@
  * Parity status (see DESIGN.md "Oracle"):
  *   - oracle_gauss_weights : PINNED against the reference's own
  *     Controller::_GenerateGausianKernel compiled from /root/reference
- *     (oracle/_ref, tests/test_oracle_ref.py) and by committed vectors that
+ *     (oracle/_ref, tests/test_oracle.py::test_weights_against_live_reference_build) and by committed vectors that
  *     build produced (tests/golden/gauss_weights_ref.json).
  *   - oracle_gray_*, oracle_gauss_rgba, oracle_sobel_* : PARITY UNPINNED.  The
  *     reference keeps those loops inside translation units that include
@@ -104,7 +104,7 @@ ORACLE_API void oracle_gray_rgba(const uint8_t *rgba, uint8_t *out_rgba, int w, 
 /* unqualified exp() on a float argument; result divided by a double          */
 /* (2*M_PI is double); stored to float; float running sum; value /= sum.      */
 /* Which exp overload the reference's build picks was decided by the real      */
-/* compile in oracle/_ref (tests/test_oracle_ref.py compares bit patterns):    */
+/* compile in oracle/_ref (tests/test_oracle.py::test_weights_against_live_reference_build compares bit patterns):    */
 /* it is ::exp(double).                                                        */
 /* ------------------------------------------------------------------------- */
 ORACLE_API int oracle_gauss_weights(int k, float sigma, float *out)

@@ -69,8 +69,9 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
     crop = np.ascontiguousarray(fixture_rgb[:96, :128])
     ppm.write_bytes(b"P6\n# fixture crop\n128 96\n255\n" + crop.tobytes())
     prefix = str(tmp_path / "out")
+    # the reference's ProgramHandler opens RealtimeImageProcessing.log in the working directory (ProgramHandler.cpp:14)
     run = subprocess.run([HOST_APP, str(raw), str(w), str(h), prefix, str(ppm)], capture_output=True, text=True,
-                         timeout=300)
+                         timeout=300, cwd=str(tmp_path))
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
     assert "host_app ok" in run.stdout
     # the reference's bootstrap chatter is preserved (Controller.cpp:25,35,62,111,127,177,189)
@@ -97,7 +98,9 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
 
 
 def _run_err(what):
-    return subprocess.run([HOST_ERRORS, what], capture_output=True, text=True, timeout=120)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:   # log files land there, not in the repository
+        return subprocess.run([HOST_ERRORS, what], capture_output=True, text=True, timeout=120, cwd=d)
 
 
 def test_logger_throws_like_the_reference(host_built):

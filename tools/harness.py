@@ -76,11 +76,19 @@ def main():
         mae = float(np.mean(np.abs(out.astype(np.int16) - ref.astype(np.int16))))
         rows.append([datetime.datetime.now().strftime("%Y-%m-%d %H:%M:%S"), os.path.basename(path), "%dx%d" % (w, h), n,
                      cpu_ms, tot / n, kern / n, wr / n, rd / n, (wr + kern + rd) / n, mae])
+    # <out>: the reference's file, byte for byte its header and its 11 columns (RT/src/FileHandler.cpp:28-32);
+    # <out>_derived.csv: the same rows plus the two columns its plotting script derives
+    # (src/GaussianBlur/results/visualisation.py:67,78: Speedup, operation_speedup)
     with open(args.out, "w", newline="") as f:
+        f.write(", ".join(HEADER) + "\n")
+        for r in rows:
+            f.write(", ".join(str(v) for v in r) + "\n")
+    derived = os.path.splitext(args.out)[0] + "_derived.csv"
+    with open(derived, "w", newline="") as f:
         f.write(", ".join(HEADER) + ", Speedup, operation_speedup\n")
         for r in rows:
             f.write(", ".join(str(v) for v in r) + ", %g, %g\n" % (r[4] / r[5], r[4] / r[9]))
-    print(open(args.out).read())
+    print(open(derived).read())
 
 
 if __name__ == "__main__":
