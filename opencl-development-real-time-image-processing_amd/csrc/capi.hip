@@ -23,6 +23,7 @@ struct CoefEntry {
     uint32_t sigma_bits;
     GaussCoef coef;
     float* d_buf;  // [k*k w2d][k w1d]
+    std::vector<float> h_tab;  // host copy of the same block (its heap storage stays put when entries move)
     uint64_t last_use;
 };
 
@@ -188,6 +189,8 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
     slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
     std::memset(slot->coef.h_w1d, 0, sizeof(slot->coef.h_w1d));
     std::memcpy(slot->coef.h_w1d, host.data() + (size_t)k * k, sizeof(float) * k);
+    slot->h_tab = host;
+    slot->coef.h_w2d = slot->h_tab.data();
     if (out)
         *out = &slot->coef;
     return MI355_OK;

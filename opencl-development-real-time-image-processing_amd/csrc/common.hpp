@@ -88,6 +88,37 @@ __device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4])
     }
 }
 
+// The same four values with the quotient taken in integer arithmetic.  With M = 4294968 = ceil(2^32 / 1000) the
+// 48-bit product S * M = floor(S / 1000) * 2^32 + (S % 1000) * 4294967.3 + 0.704 * S, S <= 255000, so
+//   q   = high 32 bits (v_mul_hi_u32_u24) = floor(S / 1000) exactly (the excess 0.704 S / 2^32 < 4.2e-5 never
+//         carries across a multiple of 1/1000), and
+//   low = low 32 bits (v_mul_u32_u24) <= 179,520 when S % 1000 == 0 and >= 4,294,967 otherwise,
+// which is the exception test for free.  Six VALU instructions per pixel instead of seven and no fp32 rounding
+// argument; used by the fused pipeline, which is VALU-bound.  mi355_selftest runs all 2^24 colours through it.
+__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4])
+{
+    constexpr uint32_t M = 4294968u;
+    uint32_t q[4], low[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t hi = __builtin_amdgcn_udot4(p[j], 0x00000201u, 0u, false);
+        const uint32_t lo = __builtin_amdgcn_udot4(p[j], 0x00724B2Bu, 0u, false);
+        const uint32_t S = (hi << 8) + lo;
+        __builtin_assume(S < (1u << 18));  // <= 255000: lets instruction selection take the 24-bit multiplies
+        q[j] = (uint32_t)(((uint64_t)S * M) >> 32);
+        low[j] = __umul24(S, M);
+    }
+    if (min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (low[j] < 1000000u)
+                q[j] = luma_px(p[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        g[j] = (float)q[j];
+}
+
 // min(255, round-half-even(sqrt(gx^2 + gy^2))) for integer-valued floats |gx|, |gy| <= 1020 — what the
 // reference computes as saturate_cast<uchar>(lrint(sqrt(s))) — in four VALU ops per pixel, packing included:
 // s = gx^2 + gy^2 is exact in fp32 (< 2^21); v_cvt_pk_u8_f32 rounds to nearest-even, saturates at 255 and

@@ -15,6 +15,7 @@ struct GaussCoef {
     const float* d_w2d;
     const float* d_w1d;
     float h_w1d[64];  // host copy, passed by value to the register-resident kernels
+    const float* h_w2d;  // host copy of w2d (owned by the context), passed by value to the fused pipeline kernel
     // true when w2d == w1d (x) w1d up to float rounding, with non-negative entries: the FAST (separable) kernels
     // may stand in for the 2-D table.  Externally installed tables that are not (mi355_ctx_set_gauss_weights) are
     // applied tap by tap by the tiled kernels, as the reference kernel applies them (RT/kernel/gaussian_base.cl:23-44).
@@ -56,7 +57,7 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
 
 hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                            int nframes, const GaussCoef& coef, bool exact, int impl);
-bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k);
+bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
 hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                              const GaussCoef& coef);
 

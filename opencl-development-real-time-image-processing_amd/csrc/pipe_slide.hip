@@ -1,24 +1,37 @@
 // pipe_slide.hip — fused gray -> Gaussian -> Sobel on RGBA8 frames, register-resident sliding window,
-// FAST Gaussian arithmetic, k in {3,5,7}, width >= 4, height >= 2 (RAGGED instantiation when width % 4 != 0
-// or the pointers are not 16-byte aligned).  gfx950 only.
+// k in {3,5,7}, width >= 4, height >= 2 (RAGGED instantiation when width % 4 != 0 or the pointers are not
+// 16-byte aligned).  gfx950 only.  BIT-EXACT with the reference's CPU chain in both Gaussian modes.
 //
 // Definition (SURVEY.md §8a "a-pipe", oracle_pipeline_rgba): exactly the composition of the three API calls
 //   g = luma(R,G,B)                                   src/Grayscale/grayscale.cpp:237
 //   b = trunc(clamp(Gaussian_k(g)))  clamp-to-edge     src/GaussianBlur/GaussianBlur.cpp:234-261 on (g,g,g,255)
 //   l = luma(b,b,b)                  RE-APPLIED        (l != b for 65 byte values)
 //   out = Sobel(l)                   reflect-101       src/EdgeDetection/EdgeDetection.cpp:219-240
-// and, because the Gaussian uses the canonical FAST op order of gauss_slide.hip / gauss_tile.hip, the output
-// is bit-identical to mi355_sobel(mi355_gauss(mi355_gray(x))) of this library (tests/test_gpu_parity.py).
+//
+// The Gaussian stage is "exact by exception" (the same idea as the luminance, common.hpp): the CPU path's value
+// is trunc(S_cpu), S_cpu = the k*k-term float sum in its own order (ky outer, kx inner, separate multiply and
+// add).  A separable fp32 evaluation S (2k multiply-adds instead of 2k*k operations) differs from S_cpu by at
+// most delta, a bound the host derives rigorously from the two tables (launch_r: rounding errors of both
+// evaluations + the mismatch of w1 (x) w1 against the 2-D table; ~3e-4 at k = 5).  So wherever S is further
+// than delta from an integer, trunc(S) IS the CPU path's byte; the few pixels within delta (6e-4 of them on
+// noise-like images) are recomputed with the CPU path's own operation sequence from the ring of gray rows the
+// wave holds anyway.  Flat regions (S sits 5e-6 below an integer) take the exact chain for every pixel: correct,
+// and ~2.5x slower there.
 //
 // One wave per (frame, band, strip of <= 62 lanes + 1 halo lane per side), a lane owns 4 pixels:
-//   row in -> luma (4 floats) -> K vertical accumulators (4 floats each) -> finished vertical sum ->
-//   horizontal taps (neighbour lanes through DPP) -> trunc -> l = LUT[b] (256-byte table in LDS: luma(b,b,b)
-//   always sits on the ambiguous S % 1000 == 0 case, so it is tabulated once per workgroup with the FP64
-//   formula) -> 3-row ring of l -> Sobel row in fp32 -> 4 bytes stored.
+//   row in -> luma (4 floats) -> ring of the last K gray rows -> vertical sums of the row whose window is complete
+//   (symmetric pair form: w[R] g_c + sum_d w[R-d] (g_{c-d} + g_{c+d}); the pair sums are exact integers, and the
+//   form reads the same whichever way the band walks) -> horizontal taps (neighbour lanes through DPP) -> S ->
+//   flag test -> [exact chain] -> trunc -> l = LUT[b] (256-byte table in LDS: luma(b,b,b) always sits on the
+//   ambiguous S % 1000 == 0 case, so it is tabulated once per workgroup with the FP64 formula) -> 3-row ring of l
+//   -> Sobel row in fp32 -> 4 bytes stored.
 // 4 B read + 1 B written per pixel; nothing intermediate touches memory (the three separate calls move
-// 8 + 8 + 5 B/px).  Border rules: gray columns/rows clamp (replicated halo lane / clamped row index); the
-// blurred image reflects: column x=-1 takes x=1 and x=w takes x=w-2 by a DPP fix-up in the two edge strips,
-// row -1 takes row 1 and row h takes row h-2 by swapping ring slots at the first / last image row.
+// 8 + 8 + 5 B/px).  Odd bands walk UPWARD: a band and its lower neighbour then reach their 2R+2 shared boundary
+// rows at the same moment (the end of both walks, or the start), and the second reader hits L2 instead of HBM.
+// Border rules: gray columns/rows clamp (replicated halo lane / clamped row index); the blurred image reflects:
+// column x=-1 takes x=1 and x=w takes x=w-2 by a DPP fix-up in the two edge strips, and a blurred row outside the
+// image is replaced by its mirror, which is the OTHER neighbour row of the Sobel stencil.
+#include <cmath>
 #include <cstdlib>
 
 #include "common.hpp"
@@ -32,8 +45,10 @@ namespace {
 constexpr int kWavesPerBlock = kSlideWavesPerBlock;
 
 template <int K>
-struct PWeights {
-    float w[K];
+struct PTables {
+    float w1[K];      // separable factor (symmetric: w1[j] == w1[K-1-j])
+    float w2[K * K];  // the reference's 2-D table, row-major [ky][kx] — read only by the exact chain
+    float delta;      // |S - S_cpu| bound
 };
 
 __device__ __forceinline__ float dppl(float v)  // lane l <- lane l-1
@@ -48,13 +63,36 @@ __device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
                               __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
 }
 
+// The CPU path's own sum for pixel J of every lane (GaussianBlur.cpp:243-256: ky outer, kx inner, float multiply
+// then float add, starting from 0), from the ring of gray rows: the window's arrival rows sit in slots
+// (u + 1 + t) % K, t = 0 .. K-1, and the rows are visited in IMAGE order, top to bottom — arrival order for a band
+// walking down, the reverse for a band walking up (UP).  u is a constant after unrolling, so every register index
+// is static.  Runs under a wave-uniform branch: EXEC is full, the DPP reads see every lane.
+template <int K, int J, bool UP>
+__device__ __forceinline__ float exact_sum(const float (&g)[K][4], int u, const float* __restrict__ w2)
+{
+    constexpr int R = K / 2;
+    float sum = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < K; ky++) {
+        const float* r = g[(u + 1 + (UP ? K - 1 - ky : ky)) % K];
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) {
+            const int col = J - R + kx;
+            const float val = (col < 0) ? dppl(r[4 + col]) : ((col > 3) ? dppr(r[col - 4]) : r[col]);
+            sum = sum + val * w2[ky * K + kx];  // -ffp-contract=off: v_mul_f32 then v_add_f32
+        }
+    }
+    return sum;
+}
+
 // RAGGED = width % 4 != 0 or unaligned buffers (see gauss_slide.hip / sobel_slide.hip): unaligned 16-byte row
 // accesses in interior strips, per-pixel clamped loads and per-byte stores in the two edge strips, and the
 // reflected column x = w of the blurred image may sit anywhere inside a lane.
 template <int R, bool CLAMP, bool RAGGED>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips,
-    int lanes_out, BandPlan plan, PWeights<2 * R + 1> wts)
+    int lanes_out, BandPlan plan, PTables<2 * R + 1> tab)
 {
     constexpr int K = 2 * R + 1;
     __shared__ uint8_t lut[256];  // lut[b] = luma(b, b, b), the reference double-precision formula
@@ -67,6 +105,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
         return;  // (pipeline: after the only barrier)
     const int strip = it.strip, y0 = it.y0, nout = it.nout;
     const size_t frame = it.frame;
+    const bool up = (it.band & 1) != 0;  // wave-uniform
 
     const int q_lane = strip * lanes_out + lane - 1;
     const int quads = (w + 3) >> 2;
@@ -78,8 +117,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
 
-    // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R
+    // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R;
+    // "arrival index" i = 0 .. nin-1 counts them in walking order (top down, or bottom up for odd bands)
     const int nin = nout + 2 + 2 * R;
+    const int y_first = up ? y0 + nout + R : y0 - 1 - R;
+    const int y_step = up ? -1 : 1;
 
     const size_t row_bytes = (size_t)w * 4;
     const auto fin = uniform_ptr(in + frame * row_bytes * h);
@@ -91,13 +133,14 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     for (int j = 0; j < 4; j++)
         px_off[j] = (uint32_t)clampi(x_lane + j, 0, w - 1) * 4u;
 
-    float wv[K];
+    float wv[R + 1];  // wv[d] = weight at distance d from the centre
 #pragma unroll
-    for (int j = 0; j < K; j++)
-        wv[j] = wts.w[j];
+    for (int d = 0; d <= R; d++)
+        wv[d] = tab.w1[R - d];
+    const float delta = tab.delta, two_delta = 2.0f * tab.delta;
 
     auto load_row = [&](int i) -> u32x4 {
-        const int y = clampi(y0 - 1 - R + min(i, nin - 1), 0, h - 1);  // gray rows: clamp-to-edge
+        const int y = clampi(y_first + y_step * min(i, nin - 1), 0, h - 1);  // gray rows: clamp-to-edge
         const auto rowp = fin + (size_t)y * row_bytes;  // SGPR pair; + 32-bit lane offset = saddr form
         lane_offset_here(in_off);
         if constexpr (RAGGED) {
@@ -121,19 +164,31 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     for (int u = 0; u < PF; u++)
         q[u] = load_row(u);
 
-    float acc[K][4] = {};
-    float l[3][4] = {};  // l rows of the last three blurred rows; slot = input row index % 3
-
-    // One trip = 3K input rows, so that both rings (K vertical accumulators, 3 Sobel rows) have static slots:
-    // no register moves, no per-row selects.  K-row groups past the band's last input row are skipped.
-    for (int base = 0; base < nin; base += 3 * K) {
+    float g[K][4];  // ring of the last K gray rows; slot = arrival index % K
+    float l[3][4];  // l rows of the last three blurred rows; slot = arrival index % 3
 #pragma unroll
-        for (int u3 = 0; u3 < 3; u3++) {
-            if (base + u3 * K < nin) {  // wave-uniform
+    for (int s = 0; s < K; s++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            g[s][e] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 3; s++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+            l[s][e] = 0.0f;
+
+    // One trip = K input rows: the gray ring's slots are static (slot = u).  The 3-row ring of l starts every trip
+    // in the same phase — the previous trip's last two rows sit in slots 0 (older) and 1 (newer), row u writes slot
+    // (u + 2) % 3 — which costs 8 register moves per trip when K % 3 != 0 and keeps its slots static as well.
+    // (A 3K-row trip needs no moves, but with the exact chains in the body it is past what hipcc unrolls: it kept
+    // the ring in LDS with computed slots instead.)
+    for (int base = 0; base < nin; base += K) {
+        {
+            {
 #pragma unroll
                 for (int u = 0; u < K; u++) {
-                    const int i = base + u3 * K + u;
-                    const int s3 = (u3 * K + u) % 3;  // static after unrolling
+                    const int i = base + u;
+                    const int s3 = (u + 2) % 3;  // static after unrolling
                     u32x4 p = q[u];
                     q[(u + PF) % K] = load_row(i + PF);
                     if constexpr (!RAGGED) {
@@ -144,32 +199,62 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                                 p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
                         }
                     }
-                    float g[4];
-                    luma_quad_fast(p, g);
-                    // vertical pass (canonical order): gray row i is tap j of blurred row i - j
-#pragma unroll
-                    for (int j = 0; j < K; j++) {
-                        const int s = (u - j + K) % K;
-#pragma unroll
-                        for (int e = 0; e < 4; e++)
-                            acc[s][e] = (j == 0) ? wv[0] * g[e] : __builtin_fmaf(wv[j], g[e], acc[s][e]);
-                    }
+                    luma_quad_int(p, g[u]);
                     // Stage gating with scalar branches (i, y0, nout live in SGPRs, EXEC stays full for the DPP
-                    // reads): the first 2R rows of a band only feed the vertical accumulators, the next two only
-                    // fill the 3-row ring, and rows past the band's last output are never stored.
+                    // reads): the first 2R rows of a band only fill the gray ring, the next two only fill the
+                    // 3-row ring, and rows past the band's last output are never stored.
                     if (i >= 2 * R) {
-                        const float* v = acc[(u + 1) % K];  // vertical sum of the blurred row that just completed
-                        // horizontal pass (canonical order), neighbour-lane taps through DPP
+                        // window of the blurred row that just completed: arrival rows i-2R .. i = slots (u+1+t) % K
+                        // vertical pass, symmetric pair form (the pair sums are exact integers <= 510)
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float acc = wv[0] * g[(u + 1 + R) % K][e];
+#pragma unroll
+                            for (int d = 1; d <= R; d++)
+                                acc = __builtin_fmaf(wv[d], g[(u + 1 + R - d) % K][e] + g[(u + 1 + R + d) % K][e], acc);
+                            v[e] = acc;
+                        }
+                        // horizontal pass, same form; neighbour-lane taps through DPP
+                        // S' = S + delta rides on the centre tap, so "S within delta of an integer n" reads
+                        // "fract(S') < 2 delta", one-sided, and floor(S') = floor(S) everywhere else
+                        float S[4];
+#pragma unroll
+                        for (int px = 0; px < 4; px++) {
+                            float acc = __builtin_fmaf(wv[0], v[px], delta);
+#pragma unroll
+                            for (int d = 1; d <= R; d++) {
+                                const int a = px - d, b = px + d;
+                                const float va = (a < 0) ? dppl(v[4 + a]) : v[a];
+                                const float vb = (b > 3) ? dppr(v[b - 4]) : v[b];
+                                acc = __builtin_fmaf(wv[d], va + vb, acc);
+                            }
+                            S[px] = acc;
+                        }
+                        float t[4];  // fract is exact; S' > 0
+#pragma unroll
+                        for (int px = 0; px < 4; px++)
+                            t[px] = __builtin_amdgcn_fractf(S[px]);
+                        const float tmin = fminf(fminf(t[0], t[1]), fminf(t[2], t[3]));
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin < two_delta) != 0, 0)) {
+                            // one wave-uniform branch per pixel position: only positions some lane flagged pay
+#define MI355_EXACT_PX(J)                                                                                  \
+    if (__builtin_amdgcn_ballot_w64(t[J] < two_delta) != 0) {                                              \
+        if (up)                                                                                            \
+            S[J] = exact_sum<K, J, true>(g, u, tab.w2);                                                    \
+        else                                                                                               \
+            S[J] = exact_sum<K, J, false>(g, u, tab.w2);                                                   \
+    }
+                            MI355_EXACT_PX(0)
+                            MI355_EXACT_PX(1)
+                            MI355_EXACT_PX(2)
+                            MI355_EXACT_PX(3)
+#undef MI355_EXACT_PX
+                        }
                         float* lb = l[s3];
 #pragma unroll
                         for (int px = 0; px < 4; px++) {
-                            float sum = 0.0f;
-#pragma unroll
-                            for (int t = 0; t < K; t++) {
-                                const int s = px - R + t;
-                                const float src = (s < 0) ? dppl(v[4 + s]) : ((s > 3) ? dppr(v[s - 4]) : v[s]);
-                                sum = (t == 0) ? wv[0] * src : __builtin_fmaf(wv[t], src, sum);
-                            }
+                            float sum = S[px];
                             if constexpr (CLAMP)
                                 sum = fminf(sum, 255.0f);
                             const uint32_t bq = (uint32_t)sum;  // truncation, as the Gaussian call stores it
@@ -199,32 +284,33 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                                     lb[3] = l1;
                             }
                         }
-                        // blurred row just finished: image row yb = y0 - 1 + (i - 2R); Sobel output row m = yb - 1
-                        const int m = y0 - 2 + i - 2 * R;
-                        if (m >= y0 && m < y0 + nout) {
+                        // blurred arrival row c = i - 2R sits at image row yb(c); the Sobel row between the last
+                        // three blurred rows is m = yb(c - 1)
+                        const int c = i - 2 * R;
+                        const int m = up ? y0 + nout - c + 1 : y0 - 2 + c;
+                        if (c >= 2 && m >= y0 && m < y0 + nout) {
                             const float* lm = l[(s3 + 2) % 3];  // blurred row m
-                            const float* lt = l[(s3 + 1) % 3];  // blurred row m - 1
-                            // rows reflect too: at m = 0 the top row (-1) is row 1 = the bottom row; at m = h-1 the
-                            // bottom row (h) is row h-2 = the top row.  Wave-uniform and rare: a branch, not selects.
-                            const float* top = lt;
-                            const float* bot = lb;
+                            const float* lo = l[(s3 + 1) % 3];  // the neighbour row that arrived first
                             float cs[4], cd[4];
+                            // A neighbour row outside the image is replaced by its mirror, which is the other
+                            // neighbour (reflect-101): only at m = 0 and m = h-1.  Wave-uniform and rare: a branch.
                             if (__builtin_expect(m == 0 || m == h - 1, 0)) {
                                 // keeps this a real (never-taken) branch: hipcc otherwise if-converts both arms into
                                 // 8 v_cndmask per row on the common path
                                 asm volatile("; first / last image row");
+                                const int y_new = up ? m - 1 : m + 1;  // image row of the newest blurred row (lb)
+                                const bool new_outside = y_new < 0 || y_new >= h;
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    const float tv = (m == 0) ? lb[j] : lt[j];
-                                    const float bv = (m == h - 1) ? lt[j] : lb[j];
-                                    cs[j] = __builtin_fmaf(2.0f, lm[j], tv) + bv;
-                                    cd[j] = bv - tv;
+                                    const float nb = new_outside ? lo[j] : lb[j];  // (h >= 2: exactly one is outside)
+                                    cs[j] = __builtin_fmaf(2.0f, lm[j], nb) + nb;
+                                    cd[j] = 0.0f;
                                 }
                             } else {
 #pragma unroll
                                 for (int j = 0; j < 4; j++) {
-                                    cs[j] = __builtin_fmaf(2.0f, lm[j], top[j]) + bot[j];
-                                    cd[j] = bot[j] - top[j];
+                                    cs[j] = __builtin_fmaf(2.0f, lm[j], lo[j]) + lb[j];
+                                    cd[j] = lb[j] - lo[j];  // sign depends on the walking direction; only gy^2 is used
                                 }
                             }
                             const float csl = dppl(cs[3]), csr = dppr(cs[0]);
@@ -235,7 +321,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                             const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
                             const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
                             const float gxs[4] = {gx0, gx1, gx2, gx3}, gys[4] = {gy0, gy1, gy2, gy3};
-                    const uint32_t r = sobel_mag_quad(gxs, gys);
+                            const uint32_t r = sobel_mag_quad(gxs, gys);
                             if (stores) {
                                 const auto rowp = fout + (size_t)m * w;
                                 lane_offset_here(out_off);
@@ -257,36 +343,91 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                 }
             }
         }
+        // the last two rows written sit in slots K % 3 (older) and (K + 1) % 3 (newer): bring them to 0 and 1
+        if constexpr (K % 3 == 2) {  // K = 5: older in 2, newer in 0
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                l[1][e] = l[0][e];
+                l[0][e] = l[2][e];
+            }
+        } else if constexpr (K % 3 == 1) {  // K = 7: older in 1, newer in 2
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                l[0][e] = l[1][e];
+                l[1][e] = l[2][e];
+            }
+        }
     }
+}
+
+// u(x) = half an ulp of a float of magnitude <= x
+double half_ulp(double x)
+{
+    if (!(x > 0.0))
+        return 0.0;
+    int e = 0;
+    std::frexp(x, &e);  // x = m * 2^e, m in [0.5, 1)  ->  ulp = 2^(e - 24)
+    return std::ldexp(1.0, e - 25);
+}
+
+// |S - S_cpu| <= delta for every window of bytes, where S is the kernel's separable pair-form evaluation with w1 and
+// S_cpu the CPU path's k*k-term float sum with w2.  Everything is non-negative (checked by the caller), so partial
+// sums never exceed the final ones.
+template <int K>
+double delta_bound(const float* w1, const float* w2)
+{
+    constexpr int R = K / 2;
+    double sum2 = 0.0, max2 = 0.0, sum1 = 0.0, mismatch = 0.0;
+    for (int i = 0; i < K * K; i++) {
+        sum2 += (double)w2[i];
+        max2 = std::fmax(max2, (double)w2[i]);
+    }
+    for (int i = 0; i < K; i++)
+        sum1 += (double)w1[i];
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++)
+            mismatch += std::fabs((double)w1[i] * (double)w1[j] - (double)w2[i * K + j]);
+    // CPU path: k*k products (each rounded), k*k additions (each rounded; partial sums <= 255 * sum2)
+    const double e_cpu = K * K * half_ulp(255.0 * max2) + K * K * half_ulp(255.0 * sum2);
+    // kernel, vertical: R + 1 multiply-adds on values <= 255 * sum1 (the integer pair sums are exact)
+    const double tv = 255.0 * sum1;
+    const double e_v = (R + 1) * half_ulp(tv);
+    // kernel, horizontal: R pair sums of vertical results (<= 2 tv each, weighted), R + 1 multiply-adds on values
+    // <= 255 * sum1^2, plus the vertical error carried through weights that sum to sum1
+    double e_pairs = 0.0;
+    for (int d = 1; d <= R; d++)
+        e_pairs += (double)w1[R - d] * half_ulp(2.0 * tv);
+    // (+1: the centre tap carries + delta, one more rounding of a value of that size)
+    const double e_h = e_v * sum1 + e_pairs + (R + 2) * half_ulp(255.0 * sum1 * sum1 + 0.01);
+    return 1.25 * (e_cpu + e_h + 255.0 * mismatch) + 1e-6;
 }
 
 template <int R>
 hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
-                    const GaussCoef& coef)
+                    const GaussCoef& coef, const float* h_w2d)
 {
     constexpr int K = 2 * R + 1;
     const StripPlan sp = make_strip_plan(w);
-    // ~64 VGPRs -> 8 waves/SIMD.  Short bands win although every band spends 2R+2 warm-up rows: measured on
-    // 256 x 4K frames, k = 5 (two kinds of MI355X box): 24 rows 4.6-4.8 TB/s, 48 rows 4.4-4.6,
-    // 108 rows (the former adaptive plan) 4.1-4.4.  The kernel is not VALU-bound (removing 15 % of its VALU
-    // instructions changed nothing), short bands keep the rows that are in flight close together in memory.
     BandPlan plan;
     constexpr int kRows = (R == 1) ? 16 : (R == 2 ? 24 : 40);
     if (!make_band_plan(h, sp.nstrips, nframes, 8, kRows, kRows, kRows, 0.0, kRows / 2, &plan))
         return hipErrorInvalidValue;
-    PWeights<K> wts;
+    PTables<K> tab;
     double wsum = 0.0;
     for (int j = 0; j < K; j++) {
-        wts.w[j] = coef.h_w1d[j];
+        tab.w1[j] = coef.h_w1d[j];
         wsum += (double)coef.h_w1d[j];
     }
+    for (int j = 0; j < K * K; j++)
+        tab.w2[j] = h_w2d[j];
+    tab.delta = (float)delta_bound<K>(tab.w1, tab.w2);
     const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);
     const bool ragged = (w & 3) != 0 || (reinterpret_cast<uintptr_t>(d_in) & 15u) != 0 ||
                         (reinterpret_cast<uintptr_t>(d_out) & 3u) != 0;
     const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
 #define MI355_LAUNCH(CL, RG)                                                                                  \
     hipLaunchKernelGGL((pipe_slide_kernel<R, CL, RG>), grid, block, 0, stream, d_in, d_out, w, h, sp.nstrips,  \
-                       sp.lanes_out, plan, wts)
+                       sp.lanes_out, plan, tab)
     if (clamp && ragged)
         MI355_LAUNCH(true, true);
     else if (clamp)
@@ -301,11 +442,22 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
 
 }  // namespace
 
-bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int k)
+// The kernel needs a separable table whose factor is symmetric (the pair form) and a useful error bound; anything
+// else (only reachable through mi355_ctx_set_gauss_weights) goes to the tiled kernel.
+bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef)
 {
+    (void)d_out;
+    const int k = coef.k;
     if (k != 3 && k != 5 && k != 7)
         return false;
-    if (w < 4 || h < 2)
+    if (w < 4 || h < 2 || !coef.separable || !coef.h_w2d)
+        return false;
+    for (int j = 0; j < k / 2; j++)
+        if (coef.h_w1d[j] != coef.h_w1d[k - 1 - j])
+            return false;
+    const double delta = (k == 3) ? delta_bound<3>(coef.h_w1d, coef.h_w2d)
+                                  : (k == 5 ? delta_bound<5>(coef.h_w1d, coef.h_w2d) : delta_bound<7>(coef.h_w1d, coef.h_w2d));
+    if (!(delta < 0.01))
         return false;
     return (reinterpret_cast<uintptr_t>(d_in) & 3u) == 0;
 }
@@ -314,9 +466,9 @@ hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d
                              const GaussCoef& coef)
 {
     switch (coef.k) {
-    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef);
-    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef);
-    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef);
+    case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef, coef.h_w2d);
+    case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef, coef.h_w2d);
+    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef, coef.h_w2d);
     default: return hipErrorInvalidValue;
     }
 }

@@ -201,7 +201,9 @@ hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
 hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                            int nframes, const GaussCoef& coef, bool exact, int impl)
 {
-    if (!exact && impl != 1 && pipe_slide_supported(d_in, d_out, w, h, coef.k))
+    // the sliding-window kernel is bit-exact with the CPU chain ("exact by exception", pipe_slide.hip), so it serves
+    // both Gaussian modes; tables it cannot take (non-separable, asymmetric factor) arrive here with exact = true
+    if (impl != 1 && pipe_slide_supported(d_in, d_out, w, h, coef))
         return launch_pipe_slide(stream, d_in, d_out, w, h, nframes, coef);
     const int k = coef.k, R = k / 2;
     const int tiles_x = (w + kTW - 1) / kTW, tiles_y = (h + kTH - 1) / kTH;

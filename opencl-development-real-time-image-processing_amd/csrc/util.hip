@@ -109,12 +109,13 @@ __global__ __launch_bounds__(kThreads) void selftest_kernel(unsigned long long* 
     uint32_t bad_luma = 0, bad_mag = 0;
     for (uint32_t c = (blockIdx.x * kThreads + threadIdx.x) * 4u; c < (1u << 24); c += stride * 4u) {
         const u32x4 p = {c | 0xFF000000u, (c + 1u) | 0x7F000000u, c + 2u, (c + 3u) | 0x01000000u};
-        float g[4];
+        float g[4], gi[4];
         luma_quad_fast(p, g);
+        luma_quad_int(p, gi);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t want = luma_px(p[j]);
-            bad_luma += ((uint32_t)g[j] != want) + ((uint32_t)luma_px_fast(p[j]) != want);
+            bad_luma += ((uint32_t)g[j] != want) + ((uint32_t)luma_px_fast(p[j]) != want) + ((uint32_t)gi[j] != want);
         }
     }
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < 1021u * 1021u; i += stride) {
