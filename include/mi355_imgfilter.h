@@ -71,6 +71,10 @@ int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
  *   TILE — always the LDS-tiled kernels. */
 #define MI355_IMPL_AUTO 0
 #define MI355_IMPL_TILE 1
+/*   MFMA — the Gaussian on the matrix cores (csrc/gauss_mfma.hip) wherever it applies (FAST mode, odd k <= 17,
+ *          width % 4 == 0, 16-byte aligned device buffers); AUTO elsewhere.  Within 1 LSB of the CPU path like every
+ *          FAST kernel, but not bit-identical to the VALU kernels (other rounding). */
+#define MI355_IMPL_MFMA 2
 int mi355_ctx_set_impl(mi355_ctx* ctx, int impl);
 
 /* Input pixel format of the HOST-buffer calls (mi355_*_rgba8, mi355_filter_batched, mi355_filter_stream):

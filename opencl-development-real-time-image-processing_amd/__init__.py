@@ -13,6 +13,7 @@ from .imgfilter import (  # noqa: F401
     GAUSS_EXACT,
     GAUSS_FAST,
     IMPL_AUTO,
+    IMPL_MFMA,
     INPUT_BGR,
     INPUT_RGBA,
     IMPL_TILE,

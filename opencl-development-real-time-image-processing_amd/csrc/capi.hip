@@ -296,7 +296,7 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
         e = launch_gray(ctx->stream, in, out, w, h, nframes, true);
         break;
     case MI355_FILTER_GAUSS: {
-        const size_t nflags = gauss_flag_items(in, out, w, h, nframes, coef->k, exact, ctx->impl);
+        const size_t nflags = gauss_flag_items(in, out, w, h, nframes, *coef, exact, ctx->impl);
         if (nflags) {
             rc = ensure(ctx, &ctx->d_flags, &ctx->d_flags_cap, nflags * sizeof(uint32_t));
             if (rc != MI355_OK)
@@ -544,7 +544,7 @@ MI355_API int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode)
 
 MI355_API int mi355_ctx_set_impl(mi355_ctx* ctx, int impl)
 {
-    if (!ctx || (impl != MI355_IMPL_AUTO && impl != MI355_IMPL_TILE))
+    if (!ctx || (impl != MI355_IMPL_AUTO && impl != MI355_IMPL_TILE && impl != MI355_IMPL_MFMA))
         return MI355_ERR_BAD_ARG;
     ctx->impl = impl;
     return MI355_OK;

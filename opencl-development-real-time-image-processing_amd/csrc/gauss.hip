@@ -1,31 +1,59 @@
-// gauss.hip — Gaussian blur dispatch: picks the kernel for (k, width, mode).
+// gauss.hip — Gaussian blur dispatch: picks the kernel for (k, width, mode, impl).
+#include "../../include/mi355_imgfilter.h"
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace mi355 {
 
-size_t gauss_flag_items(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, int k, bool exact,
-                        int impl)
+namespace {
+
+enum class GaussKernel { Tile, Slide, Wide, Mfma };
+
+// AUTO: which k the matrix-core kernel takes over from the register-resident VALU kernels.  Its cost does not
+// depend on k (one K = 32 matrix instruction covers any radius <= 8), theirs grows with k: same-box measurements
+// on 4K frames are in DESIGN.md section 5 (table "Gaussian by k").
+constexpr int kMfmaAutoMinK = 99;  // not yet: set from measurements
+
+GaussKernel choose(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
+                   bool exact, int impl)
 {
-    if (exact || impl == 1)
-        return 0;
-    if (gauss_slide_supported(d_in, d_out, w, h, k))
-        return gauss_slide_flag_items(w, h, nframes, k);
-    if (gauss_wide_supported(d_in, d_out, w, h, k))
-        return gauss_wide_flag_items(w, h, nframes, k);
-    return 0;
+    // EXACT arithmetic exists only in the tiled kernel
+    if (exact || impl == MI355_IMPL_TILE)
+        return GaussKernel::Tile;
+    const bool mfma_ok = gauss_mfma_supported(d_in, d_out, w, h, coef);
+    if (impl == MI355_IMPL_MFMA && mfma_ok)
+        return GaussKernel::Mfma;
+    // a launch must be worth a 64-pixel-wide, 16-row-blocked decomposition
+    if (impl == MI355_IMPL_AUTO && mfma_ok && coef.k >= kMfmaAutoMinK && w >= 64 && (size_t)w * h * nframes >= (1u << 16))
+        return GaussKernel::Mfma;
+    if (gauss_slide_supported(d_in, d_out, w, h, coef.k))
+        return GaussKernel::Slide;
+    if (gauss_wide_supported(d_in, d_out, w, h, coef.k))
+        return GaussKernel::Wide;
+    return GaussKernel::Tile;
+}
+
+}  // namespace
+
+size_t gauss_flag_items(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
+                        bool exact, int impl)
+{
+    switch (choose(d_in, d_out, w, h, nframes, coef, exact, impl)) {
+    case GaussKernel::Slide: return gauss_slide_flag_items(w, h, nframes, coef.k);
+    case GaussKernel::Wide: return gauss_wide_flag_items(w, h, nframes, coef.k);
+    default: return 0;
+    }
 }
 
 hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                         int nframes, const GaussCoef& coef, bool exact, int impl, uint32_t* d_flags)
 {
-    // EXACT arithmetic exists only in the tiled kernel; the sliding-window kernel covers the FAST
-    // arithmetic for the small kernels and 4-pixel-aligned rows (every config in BASELINE.json).
-    if (!exact && impl != 1 && gauss_slide_supported(d_in, d_out, w, h, coef.k))
-        return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
-    if (!exact && impl != 1 && gauss_wide_supported(d_in, d_out, w, h, coef.k))
-        return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
-    return launch_gauss_tile(stream, d_in, d_out, w, h, nframes, coef, exact);
+    switch (choose(d_in, d_out, w, h, nframes, coef, exact, impl)) {
+    case GaussKernel::Mfma: return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
+    case GaussKernel::Slide: return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    case GaussKernel::Wide: return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
+    default: return launch_gauss_tile(stream, d_in, d_out, w, h, nframes, coef, exact);
+    }
 }
 
 }  // namespace mi355

@@ -1,0 +1,326 @@
+// gauss_mfma.hip — separable Gaussian blur of RGBA8 frames on the matrix cores, any odd k <= 17 (the reference
+// application's own default is k = 17, sigma = 6: include/ProgramHandler.hpp:9), width % 4 == 0.  gfx950 only.
+//
+// Why matrix cores for a stencil: at k = 17 the separable blur costs 2 * 17 * 4 = 136 multiply-adds per pixel; the
+// register-resident VALU kernel (gauss_wide.hip) is FP32-issue-bound at 2.1 TB/s (26 % of the HBM roofline).  Each
+// pass is a product with a banded (Toeplitz) matrix, and v_mfma_f32_16x16x32_f16 has K = 32 = 16 outputs + 2 * 8
+// halo taps: ONE matrix instruction blurs a 16 x 16 tile along one axis for any radius <= 8.
+//
+// Arithmetic (FAST contract: within 1 LSB per channel of the CPU path src/GaussianBlur/GaussianBlur.cpp:234-261):
+//   * pixels are bytes: exact in fp16.  Weights are fp32: each is split hi + lo (two fp16, together 22 bits) and
+//     both parts are accumulated by the matrix instruction in fp32, so pass 1 (vertical) carries ~1e-6 relative
+//     error.  Its fp32 result is split the same way (hi + lo) and pass 2 (horizontal) sums hi*Whi + lo*Whi + hi*Wlo.
+//     Both passes scale their weights by 256 so that every lo part stays a NORMAL fp16 (nothing depends on how the
+//     matrix unit treats fp16 subnormals) and the intermediate 256 * V <= 65280 still fits fp16.
+//   * the result is 65536 * sum in fp32 (< 2^24): truncation is the integer conversion followed by taking byte 2.
+//   Measured against the oracle: max |d| = 1, mismatching bytes ~1e-4 (tests/test_gpu_mfma.py).
+//
+// Layout.  A workgroup (4 waves) owns a column strip of 64 output pixels and walks down a band of 16-row blocks.
+// LDS holds the bytes of the current window as four fp16 planes (R, G, B, A), row-major, 80 columns (8 halo pixels
+// per side), in a ring of three 16-row slabs; a block reads two slabs (32 rows = 16 outputs + 8 + 8) while the
+// third is refilled.  Wave v owns the 16-pixel sub-strip v, all four channels:
+//   pass 1  D1[x][y'] = sum_y X^T[x][y] * Tv^T[y][y']   A = X^T read with ds_read_b64_tr_b16 (hardware transpose of
+//           the row-major plane), B = the banded weights (constant registers).  Two 16-column tiles (x0-8.. and
+//           x0+8..) per channel.
+//   pass 2  Z[x'][y'] = sum_x Th^T[x'][x] * D1[x][y']    the accumulator tile IS the next B operand (its row index
+//           x lives in the registers, its column y' on the lanes): no LDS round trip, no lane movement.  The k order
+//           that falls out of stacking two accumulator tiles is baked into the constant A operand.
+//   Z has y' on the lanes and 4 consecutive x' in the registers: each lane packs RGBA for 4 adjacent pixels and
+//   stores 16 bytes.
+// The MFMA k index is only a summation index, so its mapping to window rows is chosen for the LDS banks: group h of
+// 16 lanes reads window rows 4h..4h+3 and 16+4h..16+4h+3; with 160-byte rows (40 dwords) the eight rows that one
+// 32-lane half touches start at banks 0, 40, 16, 56, 32, 8, 48, 24: conflict-free.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kTX = 64;                            // output pixels per strip
+constexpr int kHalo = 8;                           // halo pixels per side (radius <= 8)
+constexpr int kCols = kTX + 2 * kHalo;             // 80 staged columns
+constexpr int kPitch = kCols;                      // fp16 elements per LDS row: 160 B
+constexpr int kSlabRows = 16;
+constexpr int kSlabElems = kSlabRows * kPitch;     // per plane
+constexpr int kPlaneElems = 3 * kSlabElems;        // ring of three slabs
+constexpr int kThreads = 256;
+
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+using lds_fp16x4 = __attribute__((address_space(3))) fp16x4;
+
+struct MWeights {
+    float w[17];  // w[8 + d], d = -8 .. 8: the separable factor centred, zero beyond the radius
+};
+
+struct MPlan {
+    int nstrips, nbands, blocks_per_band, nblocks;  // nblocks = ceil(h / 16)
+    uint32_t nwork;
+};
+
+__device__ __forceinline__ float tapw(const MWeights& W, int d)
+{
+    return (d >= -8 && d <= 8) ? W.w[8 + d] * 256.0f : 0.0f;
+}
+
+__device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// two floats -> two fp16 in one dword (v_cvt_pkrtz_f16_f32); bytes are exact under any rounding, and a
+// round-toward-zero hi part only makes the lo part non-negative
+__device__ __forceinline__ uint32_t pk16(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+__device__ __forceinline__ h8 tr_read2(const _Float16* p0, const _Float16* p1)
+{
+    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p0);
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p1);
+    h8 r;
+    __builtin_memcpy(&r, &a, 8);
+    __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &b, 8);
+    return r;
+}
+
+template <bool CLAMP>
+__global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                             int w, int h, MPlan plan, MWeights W, float alpha_top)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kPlaneElems];  // 30,720 B
+
+    const uint32_t work = xcd_remap(blockIdx.x, plan.nwork);
+    const int strip = work % plan.nstrips;
+    const int band = (work / plan.nstrips) % plan.nbands;
+    const size_t frame = work / ((uint32_t)plan.nstrips * plan.nbands);
+    const int x0 = strip * kTX;
+    const int blk0 = band * plan.blocks_per_band;
+    const int nb = min(plan.blocks_per_band, plan.nblocks - blk0);
+    const int yb0 = blk0 * 16;
+
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+    const int hgrp = l >> 4, n = l & 15, q = (l >> 2) & 3, p = l & 3;
+
+    // ---- constant operands ------------------------------------------------------------------------------------
+    // pass 1, B[k][y']: k = 8 hgrp + j sums over window row rho(k) = (j < 4 ? 4 hgrp + j : 16 + 4 hgrp + j - 4);
+    // window row rho is image row yb - 8 + rho, output row y' is yb + n
+    // pass 2, A[x'][k]: k = 8 hgrp + j sums over x = xt - 8 + 16 (j >> 2) + 4 hgrp + (j & 3); x' = xt + n
+    h8 b1hi, b1lo, a2hi, a2lo;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int rho = (j < 4) ? 4 * hgrp + j : 16 + 4 * hgrp + (j - 4);
+        _Float16 hi, lo;
+        split16(tapw(W, rho - 8 - n), hi, lo);
+        b1hi[j] = hi;
+        b1lo[j] = lo;
+        const int dx = -8 + 16 * (j >> 2) + 4 * hgrp + (j & 3) - n;
+        split16(tapw(W, dx), hi, lo);
+        a2hi[j] = hi;
+        a2lo[j] = lo;
+    }
+
+    // ---- staging: thread (r, qc) brings one row's quad qc of the 64 interior pixels, threads with qc < 4 one of the
+    // four halo quads of that row as well --------------------------------------------------------------------------
+    const int r = tid >> 4, qc = tid & 15;
+    const int col_main = kHalo + 4 * qc;                             // LDS column of the main quad
+    const int col_halo = (qc < 2) ? 4 * qc : kCols - 8 + 4 * (qc - 2);  // columns 0, 4, 72, 76
+    const bool has_halo = qc < 4;
+    const uint32_t* fin = reinterpret_cast<const uint32_t*>(in) + frame * (size_t)w * h;
+    uint32_t* fout = reinterpret_cast<uint32_t*>(out) + frame * (size_t)w * h;
+
+    auto load_quad = [&](const uint32_t* rowp, int x) -> u32x4 {
+        if (x >= 0 && x + 3 < w)
+            return *reinterpret_cast<const u32x4*>(rowp + x);  // w % 4 == 0 and x % 4 == 0: 16-byte aligned
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            v[j] = rowp[clampi(x + j, 0, w - 1)];  // clamp-to-edge columns (GaussianBlur.cpp:240)
+        return v;
+    };
+    // one px dword -> four fp16 planes: v_cvt_f32_ubyteN per byte, v_cvt_pkrtz_f16_f32 per pair.  The ALPHA plane
+    // holds 255 - A: an opaque window then blurs to exactly 0 and the output alpha is a host-evaluated constant (see
+    // the epilogue), instead of 255 * sum(w) rounding to either side of an integer.
+    auto store_quad = [&](int slot, int col, const u32x4& v) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            float f[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pxv = (c == 3) ? ~v[j] : v[j];
+                f[j] = (float)((pxv >> (8 * c)) & 0xFFu);
+            }
+            const uint2 pair = {pk16(f[0], f[1]), pk16(f[2], f[3])};
+            *reinterpret_cast<uint2*>(&lds[c * kPlaneElems + slot * kSlabElems + r * kPitch + col]) = pair;
+        }
+    };
+    u32x4 st_main, st_halo;
+    auto load_slab = [&](int s) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
+        const int y = clampi(yb0 - kHalo + 16 * s + r, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)
+        const uint32_t* rowp = fin + (size_t)y * w;
+        st_main = load_quad(rowp, x0 + 4 * qc);
+        if (has_halo)
+            st_halo = load_quad(rowp, x0 - kHalo + col_halo);
+    };
+    auto write_slab = [&](int s) {
+        const int slot = s % 3;
+        store_quad(slot, col_main, st_main);
+        if (has_halo)
+            store_quad(slot, col_halo, st_halo);
+    };
+
+    load_slab(0);
+    write_slab(0);
+    load_slab(1);
+    write_slab(1);
+    __syncthreads();
+
+    // per-lane offsets of the two transposed reads of a D1 tile (elements): row 4 hgrp + q, column 4 p
+    const int tr_off = (4 * hgrp + q) * kPitch + 4 * p + 16 * wv;
+    const int xt = x0 + 16 * wv;
+
+    for (int b = 0; b < nb; b++) {
+        const bool more = b + 1 < nb;
+        if (more)
+            load_slab(b + 2);  // in flight while this block is computed
+        const int s0 = (b % 3) * kSlabElems, s1 = ((b + 1) % 3) * kSlabElems;
+        uint32_t px[4], pz[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const _Float16* plane = &lds[c * kPlaneElems];
+            f4 d1[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const h8 a1 = tr_read2(plane + s0 + tr_off + 16 * t, plane + s1 + tr_off + 16 * t);
+                f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1hi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1lo, acc, 0, 0, 0);
+                d1[t] = acc;  // 256 * V[x = xt - 8 + 16 t + 4 hgrp + reg][y' = n]
+            }
+            // accumulator tiles -> the next B operand, split hi + lo: element 4 t + e = d1[t][e]
+            uint32_t bh[4], bl[4];
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+#pragma unroll
+                for (int e2 = 0; e2 < 2; e2++) {
+                    const float v0 = d1[t][2 * e2], v1 = d1[t][2 * e2 + 1];
+                    const uint32_t hp = pk16(v0, v1);
+                    const h2 hh = __builtin_bit_cast(h2, hp);
+                    // v - (float)hi: exact in fp32 (v_fma_mix_f32 takes the fp16 operand as it is)
+                    bh[2 * t + e2] = hp;
+                    bl[2 * t + e2] = pk16(__builtin_fmaf((float)hh[0], -1.0f, v0), __builtin_fmaf((float)hh[1], -1.0f, v1));
+                }
+            const h8 b2hi = __builtin_bit_cast(h8, u32x4{bh[0], bh[1], bh[2], bh[3]});
+            const h8 b2lo = __builtin_bit_cast(h8, u32x4{bl[0], bl[1], bl[2], bl[3]});
+            f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2hi, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2lo, b2hi, z, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2lo, z, 0, 0, 0);
+            // z = 65536 * blurred value of pixel (x' = xt + 4 hgrp + reg, y' = yb + n): the integer conversion
+            // truncates, the byte wanted is byte 2.  Alpha: the plane held 255 - A, so the value is alpha_top - z.
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                float zz = z[e];
+                if (c == 3)
+                    zz = alpha_top - zz;
+                uint32_t u = (uint32_t)zz;
+                if constexpr (CLAMP)
+                    u = min(u, 0x00FFFFFFu);
+                if (c == 0)
+                    px[e] = u;
+                else if (c == 1)
+                    px[e] = __builtin_amdgcn_perm(u, px[e], 0x0C0C0602u);   // byte 0 = R.byte2, byte 1 = G.byte2
+                else if (c == 2)
+                    pz[e] = u;
+                else
+                    px[e] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u, pz[e], 0x0C0C0602u), px[e], 0x05040100u);
+            }
+        }
+        const int yo = yb0 + 16 * b + n, xo = xt + 4 * hgrp;
+        if (yo < h && xo < w) {
+            uint32_t* dst = fout + (size_t)yo * w + xo;
+            if (xo + 3 < w) {
+                __builtin_nontemporal_store(u32x4{px[0], px[1], px[2], px[3]}, reinterpret_cast<u32x4*>(dst));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (xo + e < w)
+                        dst[e] = px[e];
+            }
+        }
+        if (more)
+            write_slab(b + 2);
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+// k <= 17 odd, width a multiple of 4, 16-byte aligned buffers, a separable table whose factor keeps the scaled
+// intermediate inside fp16 (256 * 255 * sum(w1) < 65504).
+bool gauss_mfma_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef)
+{
+    (void)h;
+    if (coef.k > 17 || coef.k < 3 || !coef.separable || !coef.h_w2d)
+        return false;
+    if ((w & 3) != 0 || ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0)
+        return false;
+    double s = 0.0;
+    for (int j = 0; j < coef.k; j++)
+        s += (double)coef.h_w1d[j];
+    return 256.0 * 255.0 * s < 65400.0;
+}
+
+hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                             const GaussCoef& coef)
+{
+    const int R = coef.k / 2;
+    MWeights W;
+    double s = 0.0;
+    for (int d = -8; d <= 8; d++) {
+        W.w[8 + d] = (d >= -R && d <= R) ? coef.h_w1d[d + R] : 0.0f;
+        s += (double)W.w[8 + d];
+    }
+    MPlan plan;
+    plan.nstrips = (w + kTX - 1) / kTX;
+    plan.nblocks = (h + 15) / 16;
+    // ~15 blocks (240 rows) per band: 16 halo rows per band are 6.7 % extra reads; launches too small to fill the
+    // chip (256 CUs x 4 workgroups) are cut finer
+    int bpb = 15;
+    while (bpb > 2 && (size_t)plan.nstrips * ((plan.nblocks + bpb - 1) / bpb) * nframes < 2048)
+        bpb = (bpb + 1) / 2;
+    plan.blocks_per_band = bpb;
+    plan.nbands = (plan.nblocks + bpb - 1) / bpb;
+    const size_t nwork = (size_t)plan.nstrips * plan.nbands * nframes;
+    if (nwork > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    plan.nwork = (uint32_t)nwork;
+    const bool clamp = !(255.0 * s * s * 1.0001 < 256.0);
+    // Alpha of an opaque window: what the CPU path computes for 255 everywhere — its own k*k-term float chain
+    // (GaussianBlur.cpp:243-256; capi.hip is built with -ffp-contract=off, so this is a float multiply and a float
+    // add per tap) — e.g. 254 for the reference's tables, whose weights sum to just under 1.  The kernel blurs
+    // 255 - A and subtracts from alpha_top, chosen so that a zero blur lands on that byte.
+    float chain = 0.0f;
+    for (int i = 0; i < coef.k * coef.k; i++)
+        chain += 255.0f * coef.h_w2d[i];
+    const int c255 = (int)(chain < 0.0f ? 0.0f : (chain > 255.0f ? 255.0f : chain));
+    double top = 255.0 * s * s * 65536.0;
+    const double lo_lim = c255 * 65536.0 + 1.0, hi_lim = (c255 + 1) * 65536.0 - 8.0;
+    top = top < lo_lim ? lo_lim : (top > hi_lim ? hi_lim : top);
+    const float alpha_top = (float)top;
+    if (clamp)
+        hipLaunchKernelGGL(gauss_mfma_kernel<true>, dim3(plan.nwork), dim3(kThreads), 0, stream, d_in, d_out, w, h, plan, W,
+                           alpha_top);
+    else
+        hipLaunchKernelGGL(gauss_mfma_kernel<false>, dim3(plan.nwork), dim3(kThreads), 0, stream, d_in, d_out, w, h, plan, W,
+                           alpha_top);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -25,11 +25,11 @@ struct GaussCoef {
 hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                        int nframes, bool one_channel);
 
-// impl: 0 = choose (sliding window when supported), 1 = force the LDS-tiled kernel.
+// impl: 0 = choose, 1 = force the LDS-tiled kernel, 2 = the matrix-core kernel wherever it applies.
 // d_flags: device scratch of gauss_flag_items(...) uint32 (one per work item of the two-kernel opaque/fallback
 // scheme, see gauss_wide.hip); may be null when that returns 0.
-size_t gauss_flag_items(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, int k, bool exact,
-                        int impl);
+size_t gauss_flag_items(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
+                        bool exact, int impl);
 hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                         int nframes, const GaussCoef& coef, bool exact, int impl, uint32_t* d_flags);
 
@@ -48,6 +48,11 @@ bool gauss_wide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int 
 size_t gauss_wide_flag_items(int w, int h, int nframes, int k);
 hipError_t launch_gauss_wide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                              const GaussCoef& coef, uint32_t* d_flags);
+
+// matrix-core kernel (gauss_mfma.hip): any odd k <= 17, width % 4 == 0, 16-byte aligned buffers, FAST arithmetic
+bool gauss_mfma_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
+hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                             const GaussCoef& coef);
 
 // impl: 0 = choose (sliding window when width % 4 == 0 and buffers aligned), 1 = force the LDS-tiled kernel
 hipError_t launch_sobel(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,

@@ -1,0 +1,76 @@
+"""GPU suite (-m gpu): the matrix-core Gaussian (csrc/gauss_mfma.hip, MI355_IMPL_MFMA) against the oracle.
+
+Contract: FAST arithmetic, |d| <= 1 LSB per channel against the CPU path (src/GaussianBlur/GaussianBlur.cpp:234-261)
+on every shape; the fp16 hi + lo splits keep the error of the sums near 1e-4, so the share of bytes that differ at
+all stays small (asserted: < 0.5 %)."""
+import numpy as np
+import pytest
+
+from conftest import rand_rgba
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def mfma(ctx, pkg):
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_impl(pkg.IMPL_MFMA)
+    yield ctx
+    ctx.set_impl(pkg.IMPL_AUTO)
+
+
+def _check(got, ref, rate=0.005):
+    d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+    assert d.max() <= 1, int(d.max())
+    if d.size >= 4096:
+        assert (d != 0).mean() < rate, float((d != 0).mean())
+
+
+def test_impulse_lands_where_the_table_says(mfma, oracle):
+    """One bright pixel per channel at different places: geometry of both passes, every tap of a k = 17 table."""
+    h, w = 80, 160
+    img = np.zeros((h, w, 4), np.uint8)
+    img[40, 70, 0] = 255
+    img[17, 5, 1] = 255      # near the left edge: clamp-to-edge columns
+    img[2, 150, 2] = 200     # near the top edge
+    img[79, 159, 3] = 255    # corner
+    for k, sigma in ((17, 6.0), (5, 1.5), (3, 0.8), (9, 2.5)):
+        _check(mfma.gauss(img, k, sigma), oracle.gauss_rgba(img, k, sigma), rate=1.0)
+
+
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0), (9, 2.5), (11, 3.0), (13, 3.3), (15, 4.0), (17, 6.0)])
+@pytest.mark.parametrize("h,w", [(1, 4), (3, 8), (16, 64), (17, 68), (40, 252), (61, 112), (131, 500), (200, 640),
+                                 (300, 1920), (9, 3840)])
+def test_mfma_gaussian_shapes(mfma, oracle, k, sigma, h, w):
+    img = rand_rgba(h, w, seed=h * 7 + w + k, alpha=None)
+    _check(mfma.gauss(img, k, sigma), oracle.gauss_rgba(img, k, sigma, threads=8))
+
+
+def test_mfma_gaussian_batches_bands_and_smooth_frames(mfma, oracle):
+    frames = oracle.synth_rgba(1000, 520, 3, first_frame=1, mode=1)     # 3 bands of 240 rows, 16 strips, ragged last strip
+    got = mfma.gauss(frames, 17, 6.0)
+    for f in range(3):
+        _check(got[f], oracle.gauss_rgba(frames[f], 17, 6.0, threads=8))
+    flat = np.full((100, 128, 4), 255, np.uint8)
+    out = mfma.gauss(flat, 17, 6.0)
+    assert set(np.unique(out).tolist()) <= {254, 255}
+    assert np.array_equal(mfma.gauss(np.zeros((50, 64, 4), np.uint8), 17, 6.0), np.zeros((50, 64, 4), np.uint8))
+
+
+def test_mfma_full_frames(mfma, oracle):
+    for (w, h, k, sigma) in ((1920, 1080, 17, 6.0), (3840, 2160, 17, 6.0), (3840, 2160, 5, 1.5), (3840, 2160, 11, 3.0)):
+        frame = oracle.synth_rgba(w, h, 1, first_frame=k, mode=1)[0]
+        _check(mfma.gauss(frame, k, sigma), oracle.gauss_rgba(frame, k, sigma, threads=16))
+    noisy = rand_rgba(1080, 1920, seed=3, alpha=None)
+    _check(mfma.gauss(noisy, 17, 6.0), oracle.gauss_rgba(noisy, 17, 6.0, threads=16))
+
+
+def test_mfma_falls_back_where_it_does_not_apply(mfma, pkg, oracle):
+    """Widths that are not multiples of 4, k > 17, EXACT mode: IMPL_MFMA behaves like AUTO."""
+    img = rand_rgba(33, 251, seed=5, alpha=None)
+    _check(mfma.gauss(img, 17, 6.0), oracle.gauss_rgba(img, 17, 6.0))
+    img = rand_rgba(40, 64, seed=6, alpha=None)
+    _check(mfma.gauss(img, 31, 10.0), oracle.gauss_rgba(img, 31, 10.0))
+    mfma.set_gauss_mode(pkg.GAUSS_EXACT)
+    assert np.array_equal(mfma.gauss(img, 17, 6.0), oracle.gauss_rgba(img, 17, 6.0))
+    mfma.set_gauss_mode(pkg.GAUSS_FAST)
