@@ -30,6 +30,8 @@
 // The MFMA k index is only a summation index, so its mapping to window rows is chosen for the LDS banks: group h of
 // 16 lanes reads window rows 4h..4h+3 and 16+4h..16+4h+3; with 160-byte rows (40 dwords) the eight rows that one
 // 32-lane half touches start at banks 0, 40, 16, 56, 32, 8, 48, 24: conflict-free.
+#include <type_traits>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -62,10 +64,7 @@ struct MPlan {
     uint32_t nwork;
 };
 
-__device__ __forceinline__ float tapw(const MWeights& W, int d)
-{
-    return (d >= -8 && d <= 8) ? W.w[8 + d] * 256.0f : 0.0f;
-}
+constexpr int kTapPad = 40;  // taps are looked up at distances -39 .. +39: a zero-padded table, no branches
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo)
 {
@@ -80,10 +79,24 @@ __device__ __forceinline__ uint32_t pk16(float a, float b)
     return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 
-__device__ __forceinline__ h8 tr_read2(const _Float16* p0, const _Float16* p1)
+// v - (float)half of hp, exact in fp32, in ONE instruction: v_fma_mix_f32 reads the fp16 operand as it is
+// (op_sel_hi marks src0 as fp16, op_sel picks its high or low half).  hipcc emits v_cvt_f32_f16 + v_sub_f32.
+template <int HALF>
+__device__ __forceinline__ float residual(uint32_t hp, float v)
 {
-    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p0);
-    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)p1);
+    float r;
+    if constexpr (HALF == 0)
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+    else
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hp), "v"(v));
+    return r;
+}
+
+// a0 / a1: LDS byte addresses (one VGPR each per block); off: compile-time byte offset -> the instruction's offset field
+__device__ __forceinline__ h8 tr_read2(uint32_t a0, uint32_t a1, int off)
+{
+    const fp16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(uintptr_t)(a0 + off));
+    const fp16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_fp16x4*)(uintptr_t)(a1 + off));
     h8 r;
     __builtin_memcpy(&r, &a, 8);
     __builtin_memcpy(reinterpret_cast<char*>(&r) + 8, &b, 8);
@@ -92,9 +105,20 @@ __device__ __forceinline__ h8 tr_read2(const _Float16* p0, const _Float16* p1)
 
 template <bool CLAMP>
 __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                             int w, int h, MPlan plan, MWeights W, float alpha_top)
+                                                             int w, int h, MPlan plan, MWeights W, float alpha_top,
+                                                             float plane_bias)
 {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kPlaneElems];  // 30,720 B
+    __shared__ float wtab[2 * kTapPad];  // wtab[kTapPad + d] = 256 * w(d), zero beyond the radius
+    if (threadIdx.x < 2 * kTapPad) {
+        const int d = (int)threadIdx.x - kTapPad;
+        float v = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 17; t++)  // kernarg reads with static indices: no scratch, no divergence
+            v = (d == t - 8) ? W.w[t] * 256.0f : v;
+        wtab[threadIdx.x] = v;
+    }
+    __syncthreads();
 
     const uint32_t work = xcd_remap(blockIdx.x, plan.nwork);
     const int strip = work % plan.nstrips;
@@ -117,11 +141,11 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
     for (int j = 0; j < 8; j++) {
         const int rho = (j < 4) ? 4 * hgrp + j : 16 + 4 * hgrp + (j - 4);
         _Float16 hi, lo;
-        split16(tapw(W, rho - 8 - n), hi, lo);
+        split16(wtab[kTapPad + rho - 8 - n], hi, lo);
         b1hi[j] = hi;
         b1lo[j] = lo;
         const int dx = -8 + 16 * (j >> 2) + 4 * hgrp + (j & 3) - n;
-        split16(tapw(W, dx), hi, lo);
+        split16(wtab[kTapPad + dx], hi, lo);
         a2hi[j] = hi;
         a2lo[j] = lo;
     }
@@ -135,129 +159,141 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
     const uint32_t* fin = reinterpret_cast<const uint32_t*>(in) + frame * (size_t)w * h;
     uint32_t* fout = reinterpret_cast<uint32_t*>(out) + frame * (size_t)w * h;
 
-    auto load_quad = [&](const uint32_t* rowp, int x) -> u32x4 {
-        if (x >= 0 && x + 3 < w)
-            return *reinterpret_cast<const u32x4*>(rowp + x);  // w % 4 == 0 and x % 4 == 0: 16-byte aligned
-        u32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            v[j] = rowp[clampi(x + j, 0, w - 1)];  // clamp-to-edge columns (GaussianBlur.cpp:240)
-        return v;
-    };
-    // one px dword -> four fp16 planes: v_cvt_f32_ubyteN per byte, v_cvt_pkrtz_f16_f32 per pair.  The ALPHA plane
-    // holds 255 - A: an opaque window then blurs to exactly 0 and the output alpha is a host-evaluated constant (see
-    // the epilogue), instead of 255 * sum(w) rounding to either side of an integer.
-    auto store_quad = [&](int slot, int col, const u32x4& v) {
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            float f[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t pxv = (c == 3) ? ~v[j] : v[j];
-                f[j] = (float)((pxv >> (8 * c)) & 0xFFu);
-            }
-            const uint2 pair = {pk16(f[0], f[1]), pk16(f[2], f[3])};
-            *reinterpret_cast<uint2*>(&lds[c * kPlaneElems + slot * kSlabElems + r * kPitch + col]) = pair;
-        }
-    };
-    u32x4 st_main, st_halo;
-    auto load_slab = [&](int s) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
-        const int y = clampi(yb0 - kHalo + 16 * s + r, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)
-        const uint32_t* rowp = fin + (size_t)y * w;
-        st_main = load_quad(rowp, x0 + 4 * qc);
-        if (has_halo)
-            st_halo = load_quad(rowp, x0 - kHalo + col_halo);
-    };
-    auto write_slab = [&](int s) {
-        const int slot = s % 3;
-        store_quad(slot, col_main, st_main);
-        if (has_halo)
-            store_quad(slot, col_halo, st_halo);
-    };
-
-    load_slab(0);
-    write_slab(0);
-    load_slab(1);
-    write_slab(1);
-    __syncthreads();
-
-    // per-lane offsets of the two transposed reads of a D1 tile (elements): row 4 hgrp + q, column 4 p
-    const int tr_off = (4 * hgrp + q) * kPitch + 4 * p + 16 * wv;
-    const int xt = x0 + 16 * wv;
-
-    for (int b = 0; b < nb; b++) {
-        const bool more = b + 1 < nb;
-        if (more)
-            load_slab(b + 2);  // in flight while this block is computed
-        const int s0 = (b % 3) * kSlabElems, s1 = ((b + 1) % 3) * kSlabElems;
-        uint32_t px[4], pz[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const _Float16* plane = &lds[c * kPlaneElems];
-            f4 d1[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                const h8 a1 = tr_read2(plane + s0 + tr_off + 16 * t, plane + s1 + tr_off + 16 * t);
-                f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1hi, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1lo, acc, 0, 0, 0);
-                d1[t] = acc;  // 256 * V[x = xt - 8 + 16 t + 4 hgrp + reg][y' = n]
-            }
-            // accumulator tiles -> the next B operand, split hi + lo: element 4 t + e = d1[t][e]
-            uint32_t bh[4], bl[4];
-#pragma unroll
-            for (int t = 0; t < 2; t++)
-#pragma unroll
-                for (int e2 = 0; e2 < 2; e2++) {
-                    const float v0 = d1[t][2 * e2], v1 = d1[t][2 * e2 + 1];
-                    const uint32_t hp = pk16(v0, v1);
-                    const h2 hh = __builtin_bit_cast(h2, hp);
-                    // v - (float)hi: exact in fp32 (v_fma_mix_f32 takes the fp16 operand as it is)
-                    bh[2 * t + e2] = hp;
-                    bl[2 * t + e2] = pk16(__builtin_fmaf((float)hh[0], -1.0f, v0), __builtin_fmaf((float)hh[1], -1.0f, v1));
+    // Workgroup-uniform: every staged column of this strip lies inside the image (INTERIOR) or not.  The walk is
+    // instantiated twice and entered through one scalar branch: with the clamped-load path as a sibling branch
+    // INSIDE the loop, hipcc waits for all outstanding memory operations — the previous block's stores included —
+    // before every load (the two paths share destination registers).
+    auto walk = [&](auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
+        auto load_quad = [&](const uint32_t* rowp, int x) -> u32x4 {
+            if constexpr (INTERIOR)
+                return *reinterpret_cast<const u32x4*>(rowp + x);  // w % 4 == 0 and x % 4 == 0: 16-byte aligned
+            u32x4 v;
+    #pragma unroll
+            for (int j = 0; j < 4; j++)
+                v[j] = rowp[clampi(x + j, 0, w - 1)];  // clamp-to-edge columns (GaussianBlur.cpp:240)
+            return v;
+        };
+        // Four px dwords -> four fp16 planes in two instructions per pair of values: a byte b placed under the
+        // exponent byte 0x64 IS the fp16 number 1024 + b (v_perm_b32 gathers the two bytes, v_or_b32 adds the
+        // exponents).  The constant 1024 each value carries comes out of pass 1 as 1024 * (sum of the pass-1 weights),
+        // the same for every output, and is cancelled by the accumulator's initial value (plane_bias).
+        // The ALPHA plane holds 1024 + (255 - A) (0x64FF64FF minus the gathered bytes, no borrow): an opaque window
+        // then blurs to exactly 0 and the output alpha is a host-evaluated constant (see the epilogue), instead of
+        // 255 * sum(w) rounding to either side of an integer.
+        auto store_quad = [&](int slot, int col, const u32x4& v) {
+    #pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t sel = 0x0C000C00u | (uint32_t)c | ((uint32_t)(4 + c) << 16);  // (0, S0.byte c, 0, S1.byte c)
+                uint32_t lo = __builtin_amdgcn_perm(v[1], v[0], sel), hi = __builtin_amdgcn_perm(v[3], v[2], sel);
+                if (c == 3) {
+                    lo = 0x64FF64FFu - lo;
+                    hi = 0x64FF64FFu - hi;
+                } else {
+                    lo |= 0x64006400u;
+                    hi |= 0x64006400u;
                 }
-            const h8 b2hi = __builtin_bit_cast(h8, u32x4{bh[0], bh[1], bh[2], bh[3]});
-            const h8 b2lo = __builtin_bit_cast(h8, u32x4{bl[0], bl[1], bl[2], bl[3]});
-            f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2hi, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2lo, b2hi, z, 0, 0, 0);
-            z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2lo, z, 0, 0, 0);
-            // z = 65536 * blurred value of pixel (x' = xt + 4 hgrp + reg, y' = yb + n): the integer conversion
-            // truncates, the byte wanted is byte 2.  Alpha: the plane held 255 - A, so the value is alpha_top - z.
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                float zz = z[e];
-                if (c == 3)
-                    zz = alpha_top - zz;
-                uint32_t u = (uint32_t)zz;
-                if constexpr (CLAMP)
-                    u = min(u, 0x00FFFFFFu);
-                if (c == 0)
-                    px[e] = u;
-                else if (c == 1)
-                    px[e] = __builtin_amdgcn_perm(u, px[e], 0x0C0C0602u);   // byte 0 = R.byte2, byte 1 = G.byte2
-                else if (c == 2)
-                    pz[e] = u;
-                else
-                    px[e] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u, pz[e], 0x0C0C0602u), px[e], 0x05040100u);
+                *reinterpret_cast<uint2*>(&lds[slot * kSlabElems + r * kPitch + col + c * kPlaneElems]) = uint2{lo, hi};
             }
-        }
-        const int yo = yb0 + 16 * b + n, xo = xt + 4 * hgrp;
-        if (yo < h && xo < w) {
-            uint32_t* dst = fout + (size_t)yo * w + xo;
-            if (xo + 3 < w) {
-                __builtin_nontemporal_store(u32x4{px[0], px[1], px[2], px[3]}, reinterpret_cast<u32x4*>(dst));
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; e++)
-                    if (xo + e < w)
-                        dst[e] = px[e];
-            }
-        }
-        if (more)
-            write_slab(b + 2);
+        };
+        u32x4 st_main, st_halo;
+        auto load_slab = [&](int s) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
+            const int y = clampi(yb0 - kHalo + 16 * s + r, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)
+            const uint32_t* rowp = fin + (size_t)y * w;
+            st_main = load_quad(rowp, x0 + 4 * qc);
+            if (has_halo)
+                st_halo = load_quad(rowp, x0 - kHalo + col_halo);
+        };
+        auto write_slab = [&](int s) {
+            const int slot = s % 3;
+            store_quad(slot, col_main, st_main);
+            if (has_halo)
+                store_quad(slot, col_halo, st_halo);
+        };
+
+        load_slab(0);
+        write_slab(0);
+        load_slab(1);
+        write_slab(1);
         __syncthreads();
-    }
+
+        const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16*)lds;
+        // per-lane offsets of the two transposed reads of a D1 tile (elements): row 4 hgrp + q, column 4 p
+        const int tr_off = (4 * hgrp + q) * kPitch + 4 * p + 16 * wv;
+        const int xt = x0 + 16 * wv;
+
+        for (int b = 0; b < nb; b++) {
+            const bool more = b + 1 < nb;
+            if (more)
+                load_slab(b + 2);  // in flight while this block is computed
+            // two base pointers per block; plane and tile are immediate offsets of the reads
+            uint32_t w0 = lds_base + 2u * (uint32_t)((b % 3) * kSlabElems + tr_off);
+            uint32_t w1 = lds_base + 2u * (uint32_t)(((b + 1) % 3) * kSlabElems + tr_off);
+            asm volatile("" : "+v"(w0), "+v"(w1));  // keep them as the two bases: hipcc otherwise rebuilds every address
+            uint32_t px[4], pz[4];
+    #pragma unroll
+            for (int c = 0; c < 4; c++) {
+                f4 d1[2];
+    #pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const h8 a1 = tr_read2(w0, w1, 2 * (c * kPlaneElems + 16 * t));
+                    f4 acc = {plane_bias, plane_bias, plane_bias, plane_bias};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1hi, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1lo, acc, 0, 0, 0);
+                    d1[t] = acc;  // 256 * V[x = xt - 8 + 16 t + 4 hgrp + reg][y' = n]
+                }
+                // accumulator tiles -> the next B operand, split hi + lo: element 4 t + e = d1[t][e]
+                uint32_t bh[4], bl[4];
+    #pragma unroll
+                for (int t = 0; t < 2; t++)
+    #pragma unroll
+                    for (int e2 = 0; e2 < 2; e2++) {
+                        const float v0 = d1[t][2 * e2], v1 = d1[t][2 * e2 + 1];
+                        const uint32_t hp = pk16(v0, v1);
+                        bh[2 * t + e2] = hp;
+                        bl[2 * t + e2] = pk16(residual<0>(hp, v0), residual<1>(hp, v1));
+                    }
+                const h8 b2hi = __builtin_bit_cast(h8, u32x4{bh[0], bh[1], bh[2], bh[3]});
+                const h8 b2lo = __builtin_bit_cast(h8, u32x4{bl[0], bl[1], bl[2], bl[3]});
+                f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2hi, z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2lo, b2hi, z, 0, 0, 0);
+                z = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2hi, b2lo, z, 0, 0, 0);
+                // z = 65536 * blurred value of pixel (x' = xt + 4 hgrp + reg, y' = yb + n): the integer conversion
+                // truncates, the byte wanted is byte 2.  Alpha: the plane held 255 - A, so the value is alpha_top - z.
+    #pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    float zz = z[e];
+                    if (c == 3)
+                        zz = alpha_top - zz;
+                    uint32_t u = (uint32_t)zz;
+                    if constexpr (CLAMP)
+                        u = min(u, 0x00FFFFFFu);
+                    if (c == 0)
+                        px[e] = u;
+                    else if (c == 1)
+                        px[e] = __builtin_amdgcn_perm(u, px[e], 0x0C0C0602u);   // byte 0 = R.byte2, byte 1 = G.byte2
+                    else if (c == 2)
+                        pz[e] = u;
+                    else
+                        px[e] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u, pz[e], 0x0C0C0602u), px[e], 0x05040100u);
+                }
+            }
+            // refill first, store after: the refill waits for this block's loads, which were issued before anything
+            // else in the block; waiting after the stores would wait for the stores too (one in-order counter)
+            if (more)
+                write_slab(b + 2);
+            const int yo = yb0 + 16 * b + n, xo = xt + 4 * hgrp;
+            if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
+                __builtin_nontemporal_store(u32x4{px[0], px[1], px[2], px[3]},
+                                            reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo));
+            __syncthreads();
+        }
+    };
+    if (x0 >= kHalo && x0 + kTX + kHalo <= w)
+        walk(std::true_type{});
+    else
+        walk(std::false_type{});
 }
 
 }  // namespace
@@ -314,12 +350,21 @@ hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_in, uint8_t* d
     const double lo_lim = c255 * 65536.0 + 1.0, hi_lim = (c255 + 1) * 65536.0 - 8.0;
     top = top < lo_lim ? lo_lim : (top > hi_lim ? hi_lim : top);
     const float alpha_top = (float)top;
+    // -1024 * (sum over the 17 taps of the fp16 hi + lo parts of 256 w), as the kernel splits them
+    double bsum = 0.0;
+    for (int d = -8; d <= 8; d++) {
+        const float x = W.w[8 + d] * 256.0f;
+        const _Float16 hi = (_Float16)x;
+        const _Float16 lo = (_Float16)(x - (float)hi);
+        bsum += (double)(float)hi + (double)(float)lo;
+    }
+    const float plane_bias = (float)(-1024.0 * bsum);
     if (clamp)
         hipLaunchKernelGGL(gauss_mfma_kernel<true>, dim3(plan.nwork), dim3(kThreads), 0, stream, d_in, d_out, w, h, plan, W,
-                           alpha_top);
+                           alpha_top, plane_bias);
     else
         hipLaunchKernelGGL(gauss_mfma_kernel<false>, dim3(plan.nwork), dim3(kThreads), 0, stream, d_in, d_out, w, h, plan, W,
-                           alpha_top);
+                           alpha_top, plane_bias);
     return hipGetLastError();
 }
 
