@@ -10,9 +10,9 @@ namespace {
 enum class GaussKernel { Tile, Slide, Wide, Mfma };
 
 // AUTO: which k the matrix-core kernel takes over from the register-resident VALU kernels.  Its cost does not
-// depend on k (one K = 32 matrix instruction covers any radius <= 8), theirs grows with k: same-box measurements
-// on 4K frames are in DESIGN.md section 5 (table "Gaussian by k").
-constexpr int kMfmaAutoMinK = 99;  // not yet: set from measurements
+// depend on k (one K = 32 matrix instruction covers any radius <= 8), theirs grows with k.  Same box, 64 x 4K frames
+// (profiles/r02_mfma_table.txt): k = 9: VALU 3.99 TB/s, matrix cores 3.58; k = 11: 2.85 / 3.55; k = 17: 2.05 / 3.54.
+constexpr int kMfmaAutoMinK = 11;
 
 GaussKernel choose(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
                    bool exact, int impl)

@@ -1,18 +1,18 @@
 #!/bin/bash
 # tools/table.sh — one-box table of every kernel's steady-state rate, bench.py per row
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-row() { python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('%-44s %6.0f GB/s  %5.1f %%  %8.0f Mpx/s  %6.3f ms' % ('$*', r['achieved'], 100*r['frac'], d['value'], r['avg_launch_ms']))"; }
-python3 $ROOT/bench.py --no-cpu-baseline --filter gray 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('box: torch D2D copy ceiling %.0f GB/s' % d['roofline']['copy_ceiling_GBs'])"
+row() { python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling --no-side-figures "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; p=d.get('parity',{}); print('%-52s %6.0f GB/s  %5.1f %%  %8.0f Mpx/s  %6.3f ms  parity max|d| %s' % ('$*', r['achieved'], 100*r['frac'], d['value'], r['avg_launch_ms'], p.get('max_abs_diff')))"; }
+python3 $ROOT/bench.py --no-cpu-baseline --no-parity --filter gray 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('box: stream-copy ceiling (mi355_stream_copy_dev) %.0f GB/s' % d['roofline']['copy_ceiling_GBs'])"
 row --filter gray
 row --filter gray1
 row --filter gauss --k 3
 row --filter gauss
 row --filter gauss --random-alpha
-row --filter gauss --k 7
-row --filter gauss --k 9
-row --filter gauss --k 11 --frames 64
-row --filter gauss --k 13 --frames 64
-row --filter gauss --k 17 --frames 64
+row --filter gauss --k 7 --sigma 2.0
+row --filter gauss --k 9 --sigma 2.5
+row --filter gauss --k 11 --sigma 3.0 --frames 64
+row --filter gauss --k 13 --sigma 3.3 --frames 64
+row --filter gauss --k 17 --sigma 6 --frames 64
 row --filter sobel
 row --filter pipeline --k 3
 row --filter pipeline
@@ -23,3 +23,16 @@ row --filter pipeline --width 1023 --height 819 --frames 2048
 row --filter gauss --frames 1 --steps 300
 row --filter gauss --frames 8 --steps 200
 row --filter gauss --frames 64
+# BASELINE.json config 2 and friends: 1080p frames (1024 frames = the 4K batches' byte count)
+row --filter gauss --width 1920 --height 1080 --frames 1024
+row --filter gauss --width 1920 --height 1080 --frames 1024 --random-alpha
+row --filter sobel --width 1920 --height 1080 --frames 1024
+row --filter pipeline --width 1920 --height 1080 --frames 1024
+row --filter gauss --width 1920 --height 1080 --frames 1
+row --filter gauss --k 17 --sigma 6 --width 1920 --height 1080 --frames 256
+# config 5, N = 1 leg: 512 x 4K through the fused pipeline
+row --filter pipeline --total-frames 512
+# the matrix-core Gaussian forced at every k (AUTO takes it from k = 11)
+row --filter gauss --k 5 --frames 64 --impl mfma
+row --filter gauss --k 9 --sigma 2.5 --frames 64 --impl mfma
+row --filter gauss --k 17 --sigma 6 --frames 256
