@@ -39,14 +39,19 @@ namespace mi355 {
 
 namespace {
 
-constexpr int kTX = 64;                            // output pixels per strip
+#ifndef MI355_MFMA_TX
+#define MI355_MFMA_TX 64
+#endif
+constexpr int kTX = MI355_MFMA_TX;                 // output pixels per strip (16 per wave)
+constexpr int kWaves = kTX / 16;
+constexpr int kQuadsPerRow = kTX / 4;
 constexpr int kHalo = 8;                           // halo pixels per side (radius <= 8)
 constexpr int kCols = kTX + 2 * kHalo;             // 80 staged columns
 constexpr int kPitch = kCols;                      // fp16 elements per LDS row: 160 B
 constexpr int kSlabRows = 16;
 constexpr int kSlabElems = kSlabRows * kPitch;     // per plane
 constexpr int kPlaneElems = 3 * kSlabElems;        // ring of three slabs
-constexpr int kThreads = 256;
+constexpr int kThreads = 64 * kWaves;              // = 16 rows x kQuadsPerRow quads: one main quad per thread per slab
 
 typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -109,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
                                                              float plane_bias)
 {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kPlaneElems];  // 30,720 B
+    __shared__ uint32_t clear_flag[3 * kWaves];  // [slab slot][wave]: something non-opaque was staged
     __shared__ float wtab[2 * kTapPad];  // wtab[kTapPad + d] = 256 * w(d), zero beyond the radius
     if (threadIdx.x < 2 * kTapPad) {
         const int d = (int)threadIdx.x - kTapPad;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
 
     // ---- staging: thread (r, qc) brings one row's quad qc of the 64 interior pixels, threads with qc < 4 one of the
     // four halo quads of that row as well --------------------------------------------------------------------------
-    const int r = tid >> 4, qc = tid & 15;
+    const int r = tid / kQuadsPerRow, qc = tid % kQuadsPerRow;
     const int col_main = kHalo + 4 * qc;                             // LDS column of the main quad
     const int col_halo = (qc < 2) ? 4 * qc : kCols - 8 + 4 * (qc - 2);  // columns 0, 4, 72, 76
     const bool has_halo = qc < 4;
@@ -196,43 +202,87 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
                 *reinterpret_cast<uint2*>(&lds[slot * kSlabElems + r * kPitch + col + c * kPlaneElems]) = uint2{lo, hi};
             }
         };
-        u32x4 st_main, st_halo;
-        auto load_slab = [&](int s) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
+        // Two register sets: slab s + 2 is written to LDS at the end of block s, slab s + 3 is already on its way —
+        // loads are issued two blocks (2 x ~2.5 us) before their data is needed.  With one set (loads one block
+        // ahead) the kernel ran at the same speed with its arithmetic removed: it was bound by load latency.
+        struct Staged {
+            u32x4 main, halo;
+        };
+        Staged stA, stB;
+        auto load_slab = [&](int s, Staged& st) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
             const int y = clampi(yb0 - kHalo + 16 * s + r, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)
             const uint32_t* rowp = fin + (size_t)y * w;
-            st_main = load_quad(rowp, x0 + 4 * qc);
+            st.main = load_quad(rowp, x0 + 4 * qc);
             if (has_halo)
-                st_halo = load_quad(rowp, x0 - kHalo + col_halo);
+                st.halo = load_quad(rowp, x0 - kHalo + col_halo);
         };
-        auto write_slab = [&](int s) {
+        // Each wave also records whether anything it staged into the slab was NOT opaque (alpha != 255): when both
+        // slabs of a block are opaque in all four waves, the alpha plane is all zeros, its blur is exactly 0 and the
+        // output alpha is the constant — the block skips the alpha channel, a quarter of its matrix and vector work.
+        // (Every frame the reference hands its Controller went through cvtColor(BGR2RGBA): RT/src/ProgramHandler.cpp:127.)
+        auto write_slab = [&](int s, const Staged& st) {
             const int slot = s % 3;
-            store_quad(slot, col_main, st_main);
-            if (has_halo)
-                store_quad(slot, col_halo, st_halo);
+            store_quad(slot, col_main, st.main);
+            uint32_t a = st.main[0] & st.main[1] & st.main[2] & st.main[3];
+            if (has_halo) {
+                store_quad(slot, col_halo, st.halo);
+                a &= st.halo[0] & st.halo[1] & st.halo[2] & st.halo[3];
+            }
+            const bool wave_clear = __builtin_amdgcn_ballot_w64(a < 0xFF000000u) != 0;
+            if (l == 0)
+                clear_flag[slot * kWaves + wv] = wave_clear ? 1u : 0u;
         };
 
-        load_slab(0);
-        write_slab(0);
-        load_slab(1);
-        write_slab(1);
+        load_slab(0, stA);
+        write_slab(0, stA);
+        load_slab(1, stB);
+        write_slab(1, stB);
+        load_slab(2, stA);  // (rows clamp: harmless when the band has a single block)
         __syncthreads();
 
+        const uint32_t alpha_const = (uint32_t)alpha_top;  // byte 2 = the opaque alpha
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16*)lds;
         // per-lane offsets of the two transposed reads of a D1 tile (elements): row 4 hgrp + q, column 4 p
         const int tr_off = (4 * hgrp + q) * kPitch + 4 * p + 16 * wv;
         const int xt = x0 + 16 * wv;
 
-        for (int b = 0; b < nb; b++) {
+        // one block; `cur` holds slab b + 2 (loaded during block b - 1), `nxt` receives slab b + 3
+        uint32_t pend[4] = {0u, 0u, 0u, 0u};  // the previous block's pixels, permuted, not yet stored
+        // The block's pixels are stored at the top of the NEXT step, after that step's loads have been issued: hipcc
+        // puts s_waitcnt vmcnt(0) in front of every step's loads (their destination registers are recycled), and a
+        // store issued just before it would be waited for — with the arithmetic removed the kernel gained 27 % from
+        // dropping its stores, none from dropping half its matrix work.  Issued here, a store has a whole block to retire.
+        auto store_block = [&](int b) {
+            const int yo = yb0 + 16 * b + (l >> 2), xo = xt + 4 * (l & 3);
+            u32x4* dst = reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo);
+            if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
+                __builtin_nontemporal_store(u32x4{pend[0], pend[1], pend[2], pend[3]}, dst);
+        };
+        auto step = [&](int b, Staged& cur, Staged& nxt) {
             const bool more = b + 1 < nb;
-            if (more)
-                load_slab(b + 2);  // in flight while this block is computed
+            if (b + 2 < nb)
+                load_slab(b + 3, nxt);
+            if (b > 0)
+                store_block(b - 1);
             // two base pointers per block; plane and tile are immediate offsets of the reads
             uint32_t w0 = lds_base + 2u * (uint32_t)((b % 3) * kSlabElems + tr_off);
             uint32_t w1 = lds_base + 2u * (uint32_t)(((b + 1) % 3) * kSlabElems + tr_off);
             asm volatile("" : "+v"(w0), "+v"(w1));  // keep them as the two bases: hipcc otherwise rebuilds every address
-            uint32_t px[4], pz[4];
+            uint32_t px[4] = {0u, 0u, 0u, 0u}, pz[4] = {0u, 0u, 0u, 0u};
+            const int f0 = (b % 3) * kWaves, f1 = ((b + 1) % 3) * kWaves;
+            uint32_t any_clear = 0u;
+    #pragma unroll
+            for (int v = 0; v < kWaves; v++)
+                any_clear |= clear_flag[f0 + v] | clear_flag[f1 + v];
+            const bool opaque = __builtin_amdgcn_readfirstlane(any_clear) == 0;
     #pragma unroll
             for (int c = 0; c < 4; c++) {
+                if (c == 3 && opaque) {  // wave-uniform
+    #pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        px[e] = __builtin_amdgcn_perm(__builtin_amdgcn_perm(alpha_const, pz[e], 0x0C0C0602u), px[e], 0x05040100u);
+                    break;
+                }
                 f4 d1[2];
     #pragma unroll
                 for (int t = 0; t < 2; t++) {
@@ -282,13 +332,23 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
             // refill first, store after: the refill waits for this block's loads, which were issued before anything
             // else in the block; waiting after the stores would wait for the stores too (one in-order counter)
             if (more)
-                write_slab(b + 2);
-            const int yo = yb0 + 16 * b + n, xo = xt + 4 * hgrp;
-            if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
-                __builtin_nontemporal_store(u32x4{px[0], px[1], px[2], px[3]},
-                                            reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo));
+                write_slab(b + 2, cur);
+            // The accumulator layout leaves lane (n, hgrp) with row n, pixels 4 hgrp .. 4 hgrp + 3: neighbouring lanes
+            // hold different ROWS, and the memory pipeline merges neighbouring lanes only — every lane's 16 bytes would
+            // travel as a request of its own (WRITE_SIZE read 1.30 x the bytes stored).  One lane permutation
+            // (ds_bpermute_b32, the LDS crossbar, no LDS memory) puts the four pieces of a row on four consecutive
+            // lanes: lane L gets row L >> 2, piece L & 3, and each 64-byte row segment leaves as one request.
+    #pragma unroll
+            for (int e = 0; e < 4; e++)
+                pend[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((l & 3) * 16 + (l >> 2)), (int)px[e]);
             __syncthreads();
+        };
+        for (int b = 0; b < nb; b += 2) {
+            step(b, stA, stB);
+            if (b + 1 < nb)
+                step(b + 1, stB, stA);
         }
+        store_block(nb - 1);
     };
     if (x0 >= kHalo && x0 + kTX + kHalo <= w)
         walk(std::true_type{});
