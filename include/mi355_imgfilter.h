@@ -142,6 +142,23 @@ int mi355_sobel_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_gray, in
 int mi355_pipeline_rgba8(mi355_ctx* ctx, const uint8_t* rgba, uint8_t* out_gray, int w, int h, int k,
                          float sigma, uint64_t prof_ns[6]);
 
+/* ---- image2d_t mode ---------------------------------------------------------
+ * What the reference computes when image support is NOT bypassed (BYPASS_IMAGE_SUPPORT = false; no shipped
+ * application does that): its *_images.cl kernels and the host code around them, which differ from the buffer path
+ * in WHAT they compute —
+ *   MI355_FILTER_GRAY   RT/kernel/grayscale_images.cl:15-22 + Controller.cpp:256-258,76-85: fp32 luminance of the
+ *                       normalised texel, R/FLOAT image, host truncation of f * 255       -> out = w*h bytes
+ *   MI355_FILTER_GAUSS  RT/kernel/gaussian_images.cl:1-36 + Controller.cpp:374-403: taps outside the image read the
+ *                       border colour 0 (CLK_ADDRESS_CLAMP), no renormalisation, the image-mode table (its last row
+ *                       and column are 0), round-to-nearest into UNORM_INT8              -> out = w*h*4 bytes
+ *   MI355_FILTER_SOBEL  RT/kernel/edge_images.cl:3-47: RED channel only, interior pixels only (border 0), magnitude
+ *                       clamped to [0, 1], host truncation of f * 255                     -> out = w*h bytes
+ * Same call shape and profiling contract as the buffer-mode calls.  mi355_gauss_weights_image2d is the image-mode
+ * table generator (Controller::_GenerateGaussianKernelImage2D), bit-identical to the reference's. */
+int mi355_image2d_rgba8(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h, int k,
+                        float sigma, uint64_t prof_ns[6]);
+int mi355_gauss_weights_image2d(int k, float sigma, float* out_k2);
+
 /* Batched host-buffer form: nframes frames back to back in `rgba` and in `out`; one H2D, one launch
  * (grid.z-style frame index), one D2H.  filter: MI355_FILTER_*. */
 #define MI355_FILTER_GRAY 0     /* RGBA -> RGBA (g,g,g,255) */

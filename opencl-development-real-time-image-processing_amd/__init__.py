@@ -22,6 +22,7 @@ from .imgfilter import (  # noqa: F401
     build_library,
     declared_symbols,
     gauss_weights,
+    gauss_weights_image2d,
     library_path,
     load_library,
 )

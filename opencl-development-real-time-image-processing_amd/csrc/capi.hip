@@ -42,6 +42,7 @@ struct mi355_ctx {
     void* d_out = nullptr;
     size_t d_out_cap = 0;
     unsigned long long* d_acc = nullptr;
+    float* d_img_table = nullptr;  // image2d-mode Gaussian table (k*k floats, MI355_MAX_GAUSS_K^2 capacity)
     void* d_flags = nullptr;  // per-work-item flags of the two-kernel Gaussian (gauss_wide.hip), pooled
     size_t d_flags_cap = 0;
     // streamed path: copy streams, per-slot events and device slots (created on first use)
@@ -105,6 +106,27 @@ void gen_weights(int k, float sigma, float* out)
             const float arg = -(x * x + y * y) / (2 * sigma * sigma);
             const float value = (float)(std::exp((double)arg) / (2 * M_PI * sigma * sigma));
             out[(y + half) * k + (x + half)] = value;
+            sum += value;
+        }
+    }
+    for (int i = 0; i < k * k; i++)
+        out[i] /= sum;
+}
+
+// Controller::_GenerateGaussianKernelImage2D, RT/src/Controller.cpp:374-403: the image-mode twin.  Its loops run
+// x, y < half (one short), so the last row and the last column of the table stay 0, and the normalising sum covers
+// only the (k-1) x (k-1) entries that were written; x is the OUTER index.  Same promotion chain as gen_weights.
+void gen_weights_image2d(int k, float sigma, float* out)
+{
+    const int half = k / 2;
+    for (int i = 0; i < k * k; i++)
+        out[i] = 0.0f;
+    float sum = 0.0f;
+    for (int x = -half; x < half; x++) {
+        for (int y = -half; y < half; y++) {
+            const float arg = -((x * x + y * y) / (2 * sigma * sigma));
+            const float value = (float)(std::exp((double)arg) / (2 * M_PI * sigma * sigma));
+            out[(x + half) * k + (y + half)] = value;
             sum += value;
         }
     }
@@ -473,6 +495,8 @@ MI355_API int mi355_ctx_destroy(mi355_ctx* ctx)
         (void)hipFree(ctx->d_acc);
     if (ctx->d_flags)
         (void)hipFree(ctx->d_flags);
+    if (ctx->d_img_table)
+        (void)hipFree(ctx->d_img_table);
     for (int i = 0; i < mi355_ctx::kSlots; i++) {
         if (ctx->slot_in[i])
             (void)hipFree(ctx->slot_in[i]);
@@ -578,6 +602,65 @@ MI355_API int mi355_gauss_weights(int k, float sigma, float* out_k2)
     if (!out_k2 || !valid_k(k) || !valid_sigma(sigma))
         return MI355_ERR_BAD_ARG;
     gen_weights(k, sigma, out_k2);
+    return MI355_OK;
+}
+
+MI355_API int mi355_gauss_weights_image2d(int k, float sigma, float* out_k2)
+{
+    if (!out_k2 || !valid_k(k) || !valid_sigma(sigma))
+        return MI355_ERR_BAD_ARG;
+    gen_weights_image2d(k, sigma, out_k2);
+    return MI355_OK;
+}
+
+MI355_API int mi355_image2d_rgba8(mi355_ctx* ctx, int filter, const uint8_t* rgba, uint8_t* out, int w, int h, int k,
+                                  float sigma, uint64_t prof_ns[6])
+{
+    if (!ctx || (filter != MI355_FILTER_GRAY && filter != MI355_FILTER_GAUSS && filter != MI355_FILTER_SOBEL))
+        return MI355_ERR_BAD_ARG;
+    int rc = check_frames(rgba, out, w, h, 1);
+    if (rc != MI355_OK)
+        return rc;
+    const bool gauss = filter == MI355_FILTER_GAUSS;
+    if (gauss && (!valid_k(k) || !valid_sigma(sigma)))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npx = (size_t)w * h, in_bytes = npx * 4, out_bytes = npx * (gauss ? 4 : 1);
+    rc = ensure(ctx, &ctx->d_in, &ctx->d_in_cap, in_bytes);
+    if (rc != MI355_OK)
+        return rc;
+    rc = ensure(ctx, &ctx->d_out, &ctx->d_out_cap, out_bytes);
+    if (rc != MI355_OK)
+        return rc;
+    if (gauss) {
+        if (!ctx->d_img_table)
+            HIP_TRY(ctx, hipMalloc((void**)&ctx->d_img_table, sizeof(float) * MI355_MAX_GAUSS_K * MI355_MAX_GAUSS_K));
+        std::vector<float> table((size_t)k * k);
+        gen_weights_image2d(k, sigma, table.data());
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // a kernel in flight may still read the previous table
+        HIP_TRY(ctx, hipMemcpy(ctx->d_img_table, table.data(), sizeof(float) * table.size(), hipMemcpyHostToDevice));
+    }
+    hipStream_t s = ctx->stream;
+    const uint64_t host0 = now_ns();
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, rgba, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(ctx, launch_image2d(s, filter, static_cast<const uint8_t*>(ctx->d_in), static_cast<uint8_t*>(ctx->d_out), w, h, 1,
+                                k, ctx->d_img_table));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+    HIP_TRY(ctx, hipStreamSynchronize(s));
+    if (prof_ns) {
+        prof_ns[0] = host0;
+        for (int i = 1; i < 6; i++) {
+            float ms = 0.0f;
+            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[i]));
+            prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
+        }
+    }
     return MI355_OK;
 }
 

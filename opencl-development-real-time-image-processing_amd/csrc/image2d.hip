@@ -1,0 +1,130 @@
+// image2d.hip — the reference's image2d_t code path (BYPASS_IMAGE_SUPPORT = false), restated for
+// gfx950.  These are the semantics of the reference's *_images.cl kernels and of the host code around them, which
+// differ from the buffer path in what they compute, not only in how:
+//   grayscale  RT/kernel/grayscale_images.cl:15-22   read_imagef of an RGBA/UNORM_INT8 texel = byte / 255.0f;
+//              gray = 0.299f x + 0.587f y + 0.114f z in fp32; written to an R/FLOAT image (Controller.cpp:256-258);
+//              the host reads w*h floats and truncates f * 255.0f (ConvertToUChar, Controller.cpp:76-85) -> w*h bytes
+//   gaussian   RT/kernel/gaussian_images.cl:1-36     sampler CLK_ADDRESS_CLAMP: taps outside the image read the
+//              border colour (0,0,0,0) — NOT the edge pixel — and the sum is NOT renormalised; the table is the
+//              image-mode generator's (Controller.cpp:374-403: its loops stop one short, last row / column stay 0);
+//              write_imagef to RGBA/UNORM_INT8 = convert_uchar_sat_rte(f * 255.0f)
+//   sobel      RT/kernel/edge_images.cl:3-47         uses only .x (the RED channel / 255.0f) of each texel — it
+//              expects an already-gray image; interior pixels only (border never written: 0 here); magnitude
+//              clamped to [0, 1]; R/FLOAT image, then ConvertToUChar -> w*h bytes
+// Arithmetic: fp32, one rounding per operation, left to right as written in the .cl source (-ffp-contract=off; an
+// OpenCL compiler may contract a*b+c, so the reference itself is only defined up to that); division and square root
+// correctly rounded.  oracle_image2d_* is the CPU twin.  No shipped application takes this path (all set
+// BYPASS_IMAGE_SUPPORT = true), so the kernels are plain one-thread-per-pixel code: correctness, not bandwidth.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace mi355 {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float unorm8(uint32_t b) { return (float)b / 255.0f; }
+
+// convert_uchar_sat_rte(f * 255.0f)
+__device__ __forceinline__ uint32_t to_unorm8(float f)
+{
+    float v = f * 255.0f;
+    v = fminf(fmaxf(v, 0.0f), 255.0f);
+    return (uint32_t)__builtin_rintf(v);
+}
+
+__global__ __launch_bounds__(kThreads) void image2d_gray_kernel(const uint32_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                                size_t npx)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= npx)
+        return;
+    const uint32_t p = in[i];
+    const float x = unorm8(p & 0xFFu), y = unorm8((p >> 8) & 0xFFu), z = unorm8((p >> 16) & 0xFFu);
+    const float gray = 0.299f * x + 0.587f * y + 0.114f * z;
+    out[i] = (uint8_t)(gray * 255.0f);  // ConvertToUChar: truncation (gray <= 1.0000001 -> at most 255)
+}
+
+__global__ __launch_bounds__(kThreads) void image2d_gauss_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                 int w, int h, size_t npx, int k,
+                                                                 const float* __restrict__ table)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= npx)
+        return;
+    const size_t fpx = (size_t)w * h;
+    const size_t f = i / fpx;
+    const int y = (int)((i % fpx) / w), x = (int)(i % w);
+    const uint32_t* img = in + f * fpx;
+    const int half = k / 2;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    for (int ky = -half; ky <= half; ky++)
+        for (int kx = -half; kx <= half; kx++) {
+            const int xx = x + kx, yy = y + ky;
+            const float wt = table[(ky + half) * k + (kx + half)];
+            uint32_t p = 0u;  // CLK_ADDRESS_CLAMP: border colour (0, 0, 0, 0)
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+                p = img[(size_t)yy * w + xx];
+            s0 = s0 + wt * unorm8(p & 0xFFu);
+            s1 = s1 + wt * unorm8((p >> 8) & 0xFFu);
+            s2 = s2 + wt * unorm8((p >> 16) & 0xFFu);
+            s3 = s3 + wt * unorm8(p >> 24);
+        }
+    out[i] = to_unorm8(s0) | (to_unorm8(s1) << 8) | (to_unorm8(s2) << 16) | (to_unorm8(s3) << 24);
+}
+
+__global__ __launch_bounds__(kThreads) void image2d_sobel_kernel(const uint32_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                                 int w, int h, size_t npx)
+{
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= npx)
+        return;
+    const size_t fpx = (size_t)w * h;
+    const size_t f = i / fpx;
+    const int y = (int)((i % fpx) / w), x = (int)(i % w);
+    if (!(x >= 1 && x < w - 1 && y >= 1 && y < h - 1)) {
+        out[i] = 0;  // never written by the reference kernel
+        return;
+    }
+    const uint32_t* img = in + f * fpx;
+    const int sx[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}}, sy[3][3] = {{-1, -2, -1}, {0, 0, 0}, {1, 2, 1}};
+    float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+    for (int ky = -1; ky <= 1; ky++)
+#pragma unroll
+        for (int kx = -1; kx <= 1; kx++) {
+            const float px = unorm8(img[(size_t)(y + ky) * w + (x + kx)] & 0xFFu);  // .x: the red channel
+            gx = gx + px * (float)sx[ky + 1][kx + 1];
+            gy = gy + px * (float)sy[ky + 1][kx + 1];
+        }
+    float mag = __builtin_sqrtf(gx * gx + gy * gy);  // correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt is on)
+    mag = fminf(fmaxf(mag, 0.0f), 1.0f);
+    out[i] = (uint8_t)(mag * 255.0f);
+}
+
+}  // namespace
+
+// filter: 0 gray (out = w*h bytes), 2 gauss (out = w*h*4 bytes, d_table = k*k floats on the device), 3 sobel (w*h bytes)
+hipError_t launch_image2d(hipStream_t stream, int filter, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                          int k, const float* d_table)
+{
+    const size_t npx = (size_t)w * h * nframes;
+    const size_t blocks = (npx + kThreads - 1) / kThreads;
+    if (blocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
+    if (filter == 0) {
+        hipLaunchKernelGGL(image2d_gray_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, d_out, npx);
+    } else if (filter == 2) {
+        hipLaunchKernelGGL(image2d_gauss_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in,
+                           reinterpret_cast<uint32_t*>(d_out), w, h, npx, k, d_table);
+    } else if (filter == 3) {
+        hipLaunchKernelGGL(image2d_sobel_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, d_out, w, h, npx);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace mi355

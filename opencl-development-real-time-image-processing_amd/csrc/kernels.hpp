@@ -66,6 +66,10 @@ bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int 
 hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                              const GaussCoef& coef);
 
+// image2d_t-mode semantics of the reference (image2d.hip): filter 0 gray / 2 gauss / 3 sobel
+hipError_t launch_image2d(hipStream_t stream, int filter, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                          int k, const float* d_table);
+
 hipError_t launch_synth(hipStream_t stream, uint8_t* d_out, int w, int h, int nframes,
                         int first_frame, uint32_t seed, int mode);
 

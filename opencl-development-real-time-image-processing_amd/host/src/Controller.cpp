@@ -178,7 +178,10 @@ void Controller::Cleanup(cl_context context, cl_command_queue commandQueue, cl_p
 std::vector<float> Controller::_GenerateGausianKernel(int kernel_size, float sigma)
 {
     std::vector<float> table((size_t)std::max(kernel_size, 0) * std::max(kernel_size, 0));
-    if (mi355_gauss_weights(kernel_size, sigma, table.data()) != MI355_OK) {
+    // the dispatcher of RT/src/Controller.cpp:405-427: image-mode generator when image support is on
+    const int rc = (m_image_support == CL_TRUE) ? mi355_gauss_weights_image2d(kernel_size, sigma, table.data())
+                                                : mi355_gauss_weights(kernel_size, sigma, table.data());
+    if (rc != MI355_OK) {
         std::cerr << "Failed to create Gaussian Kernel" << std::endl;
         exit(1);
     }
@@ -201,6 +204,23 @@ void Controller::PerformCLImageGrayscaling(cl_context* context, cl_command_queue
     if (!kernel || !*kernel || (*kernel)->family != MI355_FAMILY_GRAY)
         logger.log("Failed to set kernel arguments", Logger::LogLevel::ERROR);
     uint64_t prof[6] = {};
+    if (m_image_support == CL_TRUE) {
+        // image2d_t mode (:437-510 with m_image_support == CL_TRUE): the kernel writes an R/FLOAT image, the host reads
+        // w*h floats into a zeroed vector of output_data->size() floats and truncates f * 255 — i.e. w*h gray bytes
+        // followed by zeros; the caller views it as CV_8UC1 (RT/RealtimeImageProcessing.cpp:112)
+        std::vector<unsigned char> gray(npx);
+        const int rci = mi355_image2d_rgba8(ctx, MI355_FILTER_GRAY, input_data->data(), gray.data(), width, height, 0, 0.0f,
+                                            prof);
+        if (rci != MI355_OK) {
+            logger.log(std::string("Failed when executing kernel: ") + mi355_strerror(rci), Logger::LogLevel::ERROR);
+            return;
+        }
+        std::vector<unsigned char> result(output_data->size(), 0);
+        std::copy_n(gray.begin(), std::min(result.size(), gray.size()), result.begin());
+        *output_data = std::move(result);
+        append_profile(profiling_events, prof);
+        return;
+    }
     std::vector<unsigned char> rgba(npx * 4);
     const int rc = mi355_gray_rgba8(ctx, input_data->data(), rgba.data(), width, height, prof);
     if (rc != MI355_OK) {
@@ -231,7 +251,11 @@ void Controller::PerformCLImageEdgeDetection(cl_context* context, cl_command_que
         logger.log("Failed to set kernel arguments", Logger::LogLevel::ERROR);
     uint64_t prof[6] = {};
     std::vector<unsigned char> edges(npx);
-    const int rc = mi355_sobel_rgba8(ctx, input_data->data(), edges.data(), width, height, prof);
+    // image2d_t mode: red channel only, interior only, truncation (RT/kernel/edge_images.cl:3-47)
+    const int rc = (m_image_support == CL_TRUE)
+                       ? mi355_image2d_rgba8(ctx, MI355_FILTER_SOBEL, input_data->data(), edges.data(), width, height, 0,
+                                             0.0f, prof)
+                       : mi355_sobel_rgba8(ctx, input_data->data(), edges.data(), width, height, prof);
     if (rc != MI355_OK) {
         logger.log(std::string("Failed when executing kernel: ") + mi355_strerror(rc), Logger::LogLevel::ERROR);
         return;
@@ -259,9 +283,13 @@ void Controller::PerformCLGaussianBlur(int& kernel_size, float& kernel_sigma, cl
     if (!kernel || !*kernel || (*kernel)->family != MI355_FAMILY_GAUSS)
         logger.log("Failed to set kernel arguments", Logger::LogLevel::ERROR);
     uint64_t prof[6] = {};
-    // in place into the caller's pre-sized vector (:731)
-    const int rc = mi355_gauss_rgba8(ctx, input_data->data(), output_data->data(), width, height, kernel_size,
-                                     kernel_sigma, prof);
+    // in place into the caller's pre-sized vector (:731); image2d_t mode: border-colour taps, the image-mode table,
+    // no renormalisation (RT/kernel/gaussian_images.cl:1-36, Controller.cpp:374-403,663)
+    const int rc = (m_image_support == CL_TRUE)
+                       ? mi355_image2d_rgba8(ctx, MI355_FILTER_GAUSS, input_data->data(), output_data->data(), width, height,
+                                             kernel_size, kernel_sigma, prof)
+                       : mi355_gauss_rgba8(ctx, input_data->data(), output_data->data(), width, height, kernel_size,
+                                           kernel_sigma, prof);
     if (rc != MI355_OK) {
         logger.log(std::string("Failed when executing kernel: ") + mi355_strerror(rc), Logger::LogLevel::ERROR);
         return;

@@ -78,14 +78,14 @@ HOST_API cl_int clGetDeviceInfo(cl_device_id device, cl_device_info name, size_t
         return mi355_host::put_string(buf, size, value, size_ret);
     }
     if (name == CL_DEVICE_IMAGE_SUPPORT) {
-        // No image2d_t path is built (every shipped app sets BYPASS_IMAGE_SUPPORT=true,
-        // RT/RealtimeImageProcessing.cpp:23): report CL_FALSE so both settings land on buffer semantics.
+        // The image2d_t semantics exist (csrc/image2d.hip, mi355_image2d_rgba8): an application that does NOT bypass
+        // image support (no shipped one: RT/RealtimeImageProcessing.cpp:23) gets them, as on an image-capable device.
         if (size_ret)
             *size_ret = sizeof(cl_bool);
         if (value) {
             if (size < sizeof(cl_bool))
                 return CL_INVALID_VALUE;
-            *static_cast<cl_bool*>(value) = CL_FALSE;
+            *static_cast<cl_bool*>(value) = CL_TRUE;
         }
         return CL_SUCCESS;
     }

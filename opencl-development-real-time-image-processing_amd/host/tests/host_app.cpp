@@ -130,6 +130,27 @@ int main(int argc, char** argv)
                     t_read);
         controller.Cleanup(context, queue, program, kernel);
     }
+    // BYPASS_IMAGE_SUPPORT = false (no shipped app): InitOpenCL probes CL_DEVICE_IMAGE_SUPPORT, picks
+    // the *_images.cl kernel file and switches the Controller to image2d_t semantics
+    {
+        ProgramHandler phi(1, false, false, false, false, 5, 1.5f);
+        phi.InitLogger(logger, Logger::LogLevel::ERROR, false);
+        phi.SetDeviceProperties(0, 0);
+        phi.AddKernels(GRAYSCALE_KERNELS, "GRAYSCALE");
+        phi.AddKernels(EDGE_KERNELS, "EDGE");
+        phi.AddKernels(GAUSSIAN_KERNELS, "GAUSSIAN");
+        Controller image_controller;
+        auto igray = run(phi, image_controller, logger, frame, w, h, "GRAYSCALE");
+        if (image_controller.GetImageSupport() != CL_TRUE)
+            return 6;
+        auto iedge = run(phi, image_controller, logger, frame, w, h, "EDGE");
+        auto igauss = run(phi, image_controller, logger, frame, w, h, "GAUSSIAN");
+        dump(prefix + ".img_gray", igray.data(), igray.size());
+        dump(prefix + ".img_edge", iedge.data(), iedge.size());
+        dump(prefix + ".img_gauss", igauss.data(), igauss.size());
+        auto iw = image_controller._GenerateGausianKernel(5, 1.5f);
+        dump(prefix + ".img_weights", iw.data(), iw.size() * sizeof(float));
+    }
     std::printf("host_app ok\n");
     return 0;
 }

@@ -81,6 +81,8 @@ def load_library():
         "mi355_ctx_set_impl": [_vp, _ci],
         "mi355_gauss_weights": [_ci, ctypes.c_float, _f32p],
         "mi355_ctx_set_gauss_weights": [_vp, _ci, ctypes.c_float, _f32p],
+        "mi355_gauss_weights_image2d": [_ci, ctypes.c_float, _f32p],
+        "mi355_image2d_rgba8": [_vp, _ci, _u8p, _u8p, _ci, _ci, _ci, ctypes.c_float, _u64p],
         "mi355_gray_rgba8": [_vp, _u8p, _u8p, _ci, _ci, _u64p],
         "mi355_gray1_rgba8": [_vp, _u8p, _u8p, _ci, _ci, _u64p],
         "mi355_gauss_rgba8": [_vp, _u8p, _u8p, _ci, _ci, _ci, ctypes.c_float, _u64p],
@@ -143,6 +145,14 @@ def gauss_weights(k, sigma):
     out = np.empty((k, k), np.float32) if k > 0 else np.empty((1, 1), np.float32)
     rc = load_library().mi355_gauss_weights(int(k), float(sigma), out.ctypes.data_as(_f32p))
     _check("mi355_gauss_weights", rc)
+    return out
+
+
+def gauss_weights_image2d(k, sigma):
+    """The image-mode table — replaces Controller::_GenerateGaussianKernelImage2D (last row / column zero)."""
+    out = np.empty((k, k), np.float32) if k > 0 else np.empty((1, 1), np.float32)
+    rc = load_library().mi355_gauss_weights_image2d(int(k), float(sigma), out.ctypes.data_as(_f32p))
+    _check("mi355_gauss_weights_image2d", rc)
     return out
 
 
@@ -250,6 +260,17 @@ class Context:
 
     def pipeline(self, rgba, k, sigma, profile=False):
         return self._host(FILTER_PIPELINE, rgba, k, sigma, profile=profile)
+
+    def image2d(self, filt, rgba, k=0, sigma=0.0):
+        """mi355_image2d_rgba8: the reference's image2d_t-mode semantics.  Returns (out, six timestamps)."""
+        rgba = np.ascontiguousarray(rgba, np.uint8)
+        h, w, _ = rgba.shape
+        out = np.empty((h, w, 4) if filt == FILTER_GAUSS else (h, w), np.uint8)
+        prof = (ctypes.c_uint64 * 6)()
+        rc = self._lib.mi355_image2d_rgba8(self._h, int(filt), rgba.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p),
+                                           w, h, int(k), float(sigma), prof)
+        _check("mi355_image2d_rgba8", rc, self._h)
+        return out, list(prof)
 
     def pinned_empty(self, shape, dtype=np.uint8):
         """numpy array over pinned host memory (mi355_host_alloc); release with pinned_free(arr)."""

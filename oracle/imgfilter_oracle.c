@@ -326,6 +326,106 @@ ORACLE_API int oracle_pipeline_rgba(const uint8_t *rgba, uint8_t *out, int w, in
 }
 
 /* ------------------------------------------------------------------------- */
+/* image2d_t mode — what the reference computes when image    */
+/* support is not bypassed: its *_images.cl kernels plus the host code around   */
+/* them.  These are GPU kernels: there is no CPU counterpart in the reference,  */
+/* so this is a restatement of OpenCL-C semantics (read_imagef of UNORM_INT8 =  */
+/* byte / 255.0f; write_imagef to UNORM_INT8 = convert_uchar_sat_rte(f * 255);  */
+/* CLK_ADDRESS_CLAMP = border colour 0), fp32, one rounding per operation, in   */
+/* source order.  PARITY UNPINNED except the weight table, which is pinned by   */
+/* the reference build (tests/golden/gauss_weights_ref.json, "image2d" keys).   */
+/* ------------------------------------------------------------------------- */
+/* RT/kernel/grayscale_images.cl:15-22 + Controller.cpp:76-85 (ConvertToUChar) */
+ORACLE_API void oracle_image2d_gray(const uint8_t *rgba, uint8_t *out, int w, int h)
+{
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        float x = (float)rgba[4 * i] / 255.0f, y = (float)rgba[4 * i + 1] / 255.0f, z = (float)rgba[4 * i + 2] / 255.0f;
+        float gray = 0.299f * x + 0.587f * y + 0.114f * z;
+        out[i] = (uint8_t)(gray * 255.0f);
+    }
+}
+
+/* Controller::_GenerateGaussianKernelImage2D, RT/src/Controller.cpp:374-403 */
+ORACLE_API int oracle_gauss_weights_image2d(int k, float sigma, float *out)
+{
+    if (k <= 0 || (k & 1) == 0 || !(sigma > 0.0f))
+        return -1;
+    int half = k / 2;
+    float sum = 0.0f;
+    for (int i = 0; i < k * k; i++)
+        out[i] = 0.0f;
+    for (int x = -half; x < half; x++)
+        for (int y = -half; y < half; y++) {
+            float arg = -((x * x + y * y) / (2 * sigma * sigma));
+            float value = (float)(exp((double)arg) / (2 * M_PI * sigma * sigma));
+            out[(x + half) * k + (y + half)] = value;
+            sum += value;
+        }
+    for (int i = 0; i < k * k; i++)
+        out[i] /= sum;
+    return 0;
+}
+
+static inline uint8_t to_unorm8(float f)
+{
+    float v = f * 255.0f;
+    v = v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v);
+    return (uint8_t)rintf(v); /* round to nearest even (default rounding mode) */
+}
+
+/* RT/kernel/gaussian_images.cl:17-35 */
+ORACLE_API int oracle_image2d_gauss(const uint8_t *rgba, uint8_t *out, int w, int h, int k, const float *table)
+{
+    if (w <= 0 || h <= 0 || k <= 0 || (k & 1) == 0)
+        return -1;
+    int half = k / 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            for (int ky = -half; ky <= half; ky++)
+                for (int kx = -half; kx <= half; kx++) {
+                    int xx = x + kx, yy = y + ky;
+                    float wt = table[(ky + half) * k + (kx + half)];
+                    for (int c = 0; c < 4; c++) {
+                        float px = 0.0f; /* border colour */
+                        if (xx >= 0 && xx < w && yy >= 0 && yy < h)
+                            px = (float)rgba[((size_t)yy * w + xx) * 4 + c] / 255.0f;
+                        s[c] = s[c] + wt * px;
+                    }
+                }
+            for (int c = 0; c < 4; c++)
+                out[((size_t)y * w + x) * 4 + c] = to_unorm8(s[c]);
+        }
+    return 0;
+}
+
+/* RT/kernel/edge_images.cl:12-46 + ConvertToUChar; border pixels are never written by the kernel: 0 here */
+ORACLE_API int oracle_image2d_sobel(const uint8_t *rgba, uint8_t *out, int w, int h)
+{
+    static const int sx[3][3] = {{-1, 0, 1}, {-2, 0, 2}, {-1, 0, 1}}, sy[3][3] = {{-1, -2, -1}, {0, 0, 0}, {1, 2, 1}};
+    if (w <= 0 || h <= 0)
+        return -1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint8_t v = 0;
+            if (x >= 1 && x < w - 1 && y >= 1 && y < h - 1) {
+                float gx = 0.0f, gy = 0.0f;
+                for (int ky = -1; ky <= 1; ky++)
+                    for (int kx = -1; kx <= 1; kx++) {
+                        float px = (float)rgba[((size_t)(y + ky) * w + (x + kx)) * 4] / 255.0f;
+                        gx = gx + px * (float)sx[ky + 1][kx + 1];
+                        gy = gy + px * (float)sy[ky + 1][kx + 1];
+                    }
+                float mag = sqrtf(gx * gx + gy * gy);
+                mag = mag < 0.0f ? 0.0f : (mag > 1.0f ? 1.0f : mag);
+                v = (uint8_t)(mag * 255.0f);
+            }
+            out[(size_t)y * w + x] = v;
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Synthetic frames: counter hash of               */
 /* (seed, frame, y, x); R,G,B = hash bytes 0..2, A = 255.  mode 1 = smooth    */
 /* gradient + 4 bits of noise (photographic-like, exercises truncation        */

@@ -49,6 +49,13 @@ def _load():
     lib.oracle_sobel_rgba.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
     lib.oracle_pipeline_rgba.restype = ctypes.c_int
     lib.oracle_pipeline_rgba.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]
+    lib.oracle_image2d_gray.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
+    lib.oracle_gauss_weights_image2d.restype = ctypes.c_int
+    lib.oracle_gauss_weights_image2d.argtypes = [ctypes.c_int, ctypes.c_float, _f32p]
+    lib.oracle_image2d_gauss.restype = ctypes.c_int
+    lib.oracle_image2d_gauss.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p]
+    lib.oracle_image2d_sobel.restype = ctypes.c_int
+    lib.oracle_image2d_sobel.argtypes = [_u8p, _u8p, ctypes.c_int, ctypes.c_int]
     lib.oracle_synth_rgba.argtypes = [_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_uint32, ctypes.c_int]
     lib.oracle_checksum.restype = ctypes.c_uint64
@@ -165,6 +172,41 @@ def pipeline_rgba(rgba, k, sigma=None, weights=None):
     rc = lib().oracle_pipeline_rgba(_p8(rgba), _p8(out), w, h, int(k), _pf(weights))
     if rc != 0:
         raise ValueError("oracle_pipeline_rgba rc=%d" % rc)
+    return out
+
+
+# --- image2d_t mode: restated OpenCL-C semantics of the reference's *_images.cl kernels ---------
+def image2d_gray(rgba):
+    rgba = _c(rgba)
+    h, w, _ = rgba.shape
+    out = np.empty((h, w), np.uint8)
+    lib().oracle_image2d_gray(_p8(rgba), _p8(out), w, h)
+    return out
+
+
+def gauss_weights_image2d(k, sigma):
+    out = np.empty((k, k), np.float32)
+    if lib().oracle_gauss_weights_image2d(int(k), float(sigma), _pf(out)) != 0:
+        raise ValueError("oracle_gauss_weights_image2d: bad (k, sigma)")
+    return out
+
+
+def image2d_gauss(rgba, k, sigma):
+    rgba = _c(rgba)
+    h, w, _ = rgba.shape
+    table = gauss_weights_image2d(k, sigma)
+    out = np.empty_like(rgba)
+    if lib().oracle_image2d_gauss(_p8(rgba), _p8(out), w, h, int(k), _pf(table)) != 0:
+        raise ValueError("oracle_image2d_gauss")
+    return out
+
+
+def image2d_sobel(rgba):
+    rgba = _c(rgba)
+    h, w, _ = rgba.shape
+    out = np.empty((h, w), np.uint8)
+    if lib().oracle_image2d_sobel(_p8(rgba), _p8(out), w, h) != 0:
+        raise ValueError("oracle_image2d_sobel")
     return out
 
 

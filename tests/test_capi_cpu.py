@@ -28,6 +28,19 @@ def test_host_weight_generator_matches_reference_vectors(pkg, golden_weights):
     assert n >= 15
 
 
+def test_image2d_weight_generator_matches_reference_vectors(pkg, golden_weights):
+    """mi355_gauss_weights_image2d (product code) against the reference's own image-mode generator's output."""
+    n = 0
+    for key, bits in golden_weights.items():
+        k, s, layout = key.split(",")
+        if layout != "image2d":
+            continue
+        got = pkg.gauss_weights_image2d(int(k[2:]), float(s[6:])).reshape(-1).view(np.uint32)
+        assert got.tolist() == bits, key
+        n += 1
+    assert n >= 15
+
+
 def test_argument_validation_needs_no_gpu(pkg):
     lib = pkg.load_library()
     buf = (ctypes.c_float * 9)()

@@ -343,3 +343,34 @@ def test_reference_shaped_harness(tmp_path, method, mae_bound):
         assert mae <= mae_bound
     derived = (tmp_path / "results_derived.csv").read_text().splitlines()
     assert derived[0] == REF_CSV_HEADER + ", Speedup, operation_speedup" and len(derived[1].split(", ")) == 13
+
+
+# ---- f4: image2d_t-mode semantics ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (3, 3), (17, 65), (75, 75), (131, 500), (64, 256)])
+def test_image2d_mode_semantics(ctx, pkg, oracle, h, w):
+    """mi355_image2d_rgba8 = what the reference computes with BYPASS_IMAGE_SUPPORT = false (RT/kernel/*_images.cl,
+    RT/src/Controller.cpp:246-272,374-403): bit-exact against the restated OpenCL-C semantics (oracle_image2d_*;
+    parity unpinned — the reference has no CPU twin of these GPU kernels — except the weight table, which is pinned)."""
+    img = rand_rgba(h, w, seed=h * 3 + w, alpha=None)
+    got, prof = ctx.image2d(pkg.FILTER_GRAY, img)
+    assert np.array_equal(got, oracle.image2d_gray(img))
+    assert len(prof) == 6 and all(b >= a for a, b in zip(prof, prof[1:]))
+    got, _ = ctx.image2d(pkg.FILTER_SOBEL, img)
+    assert np.array_equal(got, oracle.image2d_sobel(img))
+    for k, sigma in ((5, 1.5), (3, 0.8), (17, 6.0)):
+        got, _ = ctx.image2d(pkg.FILTER_GAUSS, img, k, sigma)
+        assert np.array_equal(got, oracle.image2d_gauss(img, k, sigma)), (k, sigma)
+    with pytest.raises(pkg.Mi355Error):
+        ctx.image2d(pkg.FILTER_PIPELINE, img)
+    with pytest.raises(pkg.Mi355Error):
+        ctx.image2d(pkg.FILTER_GAUSS, img, 4, 1.0)
+
+
+def test_image2d_mode_fixture(ctx, pkg, oracle, fixture_rgba):
+    got, _ = ctx.image2d(pkg.FILTER_GRAY, fixture_rgba)
+    assert np.array_equal(got, oracle.image2d_gray(fixture_rgba))
+    # the image path differs from the buffer path's CPU semantics by design: fp32 vs fp64 luminance, truncation of a
+    # normalised product; on a photograph they stay within one grey level of each other
+    assert np.abs(got.astype(int) - oracle.gray_rgba_1ch(fixture_rgba).astype(int)).max() <= 1
+    got, _ = ctx.image2d(pkg.FILTER_GAUSS, fixture_rgba, 5, 1.5)
+    assert np.array_equal(got, oracle.image2d_gauss(fixture_rgba, 5, 1.5))

@@ -95,6 +95,13 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
     assert prof.size == 12 and (np.diff(prof[:6].astype(np.int64)) >= 0).all() and prof[6] >= prof[5]
     rgba = np.dstack([crop, np.full(crop.shape[:2], 255, np.uint8)])
     assert np.array_equal(load(".ppm_gray", (96, 128, 4)), oracle.gray_rgba(rgba))
+    # BYPASS_IMAGE_SUPPORT = false: image2d_t semantics and output shapes ("w*h gray bytes then zeros")
+    ig = load(".img_gray", (h * w * 4,))
+    assert np.array_equal(ig[: h * w].reshape(h, w), oracle.image2d_gray(frame)) and not ig[h * w:].any()
+    assert np.array_equal(load(".img_edge", (h, w)), oracle.image2d_sobel(frame))
+    assert np.array_equal(load(".img_gauss", (h, w, 4)), oracle.image2d_gauss(frame, 5, 1.5))
+    assert np.array_equal(np.fromfile(prefix + ".img_weights", dtype=np.float32).view(np.uint32),
+                          oracle.gauss_weights_image2d(5, 1.5).reshape(-1).view(np.uint32))
 
 
 def _run_err(what):

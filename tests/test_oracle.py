@@ -236,3 +236,43 @@ def test_checksum_is_shardable(oracle):
     parts = sum(oracle.checksum(s[f], index_base=f * words_per_frame) for f in range(4)) % (1 << 64)
     assert parts == whole
     assert oracle.synth_rgba(40, 30, 1, first_frame=2).tobytes() == s[2].tobytes()
+
+
+# ---- image2d_t mode ------------------------------------------------------------------------------
+def test_image2d_weight_generator_matches_reference_vectors(oracle, golden_weights):
+    """oracle_gauss_weights_image2d against the reference's own Controller::_GenerateGaussianKernelImage2D
+    (RT/src/Controller.cpp:374-403), built from /root/reference by oracle/Makefile: PINNED."""
+    n = 0
+    for key, bits in golden_weights.items():
+        k, s, layout = key.split(",")
+        if layout != "image2d":
+            continue
+        got = oracle.gauss_weights_image2d(int(k[2:]), float(s[6:]))
+        assert got.reshape(-1).view(np.uint32).tolist() == bits, key
+        kk = int(k[2:])
+        if kk > 1:   # the generator's loops stop one short: last row and last column stay zero
+            assert not got[-1, :].any() and not got[:, -1].any()
+        n += 1
+    assert n >= 15
+
+
+def test_image2d_known_answers(oracle):
+    """Hand-derivable values of the restated *_images.cl semantics."""
+    white = np.full((6, 9, 4), 255, np.uint8)
+    # gray of white: 0.299 + 0.587 + 0.114 in fp32, times 255, truncated
+    g = np.float32(0.299) * np.float32(1) + np.float32(0.587) * np.float32(1)
+    g = np.float32(g) + np.float32(0.114) * np.float32(1)
+    assert np.unique(oracle.image2d_gray(white)).tolist() == [int(np.float32(g) * np.float32(255))]
+    assert oracle.image2d_gray(np.zeros((3, 3, 4), np.uint8)).max() == 0
+    # Sobel: border is never written (0); a vertical red step saturates the clamp: 255 on the two step columns
+    img = np.zeros((8, 12, 4), np.uint8)
+    img[:, 6:, 0] = 255
+    img[:, :, 1] = 77          # green and blue are ignored: the kernel reads .x only
+    s = oracle.image2d_sobel(img)
+    assert not s[0].any() and not s[-1].any() and not s[:, 0].any() and not s[:, -1].any()
+    assert (s[1:-1, 5:7] == 255).all() and not s[1:-1, 1:5].any() and not s[1:-1, 7:-1].any()
+    # Gaussian: taps outside the image contribute 0 and nothing is renormalised: a white image darkens at the border,
+    # and even in the interior the image-mode table (last row / column zero, weights still summing to 1) applies
+    out = oracle.image2d_gauss(white, 5, 1.5)
+    assert out[3, 4].tolist() == [255, 255, 255, 255] or out[3, 4, 0] >= 254
+    assert out[0, 0, 0] < out[3, 4, 0] and out[0, 0, 0] < 200
