@@ -69,6 +69,7 @@ struct MPlan {
     uint32_t nwork;
 };
 
+constexpr int kOutPitch = kTX + 4;                  // dwords per row of the output tile: 256 B + 16 B of padding
 constexpr int kTapPad = 40;  // taps are looked up at distances -39 .. +39: a zero-padded table, no branches
 
 __device__ __forceinline__ void split16(float x, _Float16& hi, _Float16& lo)
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
                                                              float plane_bias)
 {
     __shared__ __attribute__((aligned(16))) _Float16 lds[4 * kPlaneElems];  // 30,720 B
+    __shared__ __attribute__((aligned(16))) uint32_t otile[2 * 16 * kOutPitch];  // two output tiles, 8,704 B
     __shared__ uint32_t clear_flag[3 * kWaves];  // [slab slot][wave]: something non-opaque was staged
     __shared__ float wtab[2 * kTapPad];  // wtab[kTapPad + d] = 256 * w(d), zero beyond the radius
     if (threadIdx.x < 2 * kTapPad) {
@@ -247,16 +249,21 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         const int xt = x0 + 16 * wv;
 
         // one block; `cur` holds slab b + 2 (loaded during block b - 1), `nxt` receives slab b + 3
-        uint32_t pend[4] = {0u, 0u, 0u, 0u};  // the previous block's pixels, permuted, not yet stored
-        // The block's pixels are stored at the top of the NEXT step, after that step's loads have been issued: hipcc
-        // puts s_waitcnt vmcnt(0) in front of every step's loads (their destination registers are recycled), and a
-        // store issued just before it would be waited for — with the arithmetic removed the kernel gained 27 % from
-        // dropping its stores, none from dropping half its matrix work.  Issued here, a store has a whole block to retire.
+        // Output path.  The accumulator layout leaves lane (n, hgrp) of wave v with row n, pixels 16 v + 4 hgrp .. + 3:
+        // stored from there, a wave instruction scatters 64-byte pieces over 16 rows, and with the arithmetic removed the
+        // kernel moved its 17 GB at 4.4 TB/s, 8.5 GB of loads alone at the equivalent of 8.8: the stores were the slow
+        // half.  So a block's pixels are transposed through an LDS tile (16 rows x 64 px, rows padded by 16 bytes: the
+        // ds_write_b128 of 8 lanes lands on 32 different banks) and each wave stores 4 whole rows x 256 contiguous
+        // bytes.  Two tiles: block b's tile is read at the top of step b + 1, after that step's loads are issued, and
+        // is overwritten at the end of step b + 2 — two barriers later.
+        auto out_tile = [&](int b) { return otile + (b & 1) * (16 * kOutPitch); };
         auto store_block = [&](int b) {
-            const int yo = yb0 + 16 * b + (l >> 2), xo = xt + 4 * (l & 3);
+            const int row = tid / (kTX / 4), piece = tid % (kTX / 4);
+            const u32x4 v = *reinterpret_cast<const u32x4*>(out_tile(b) + row * kOutPitch + 4 * piece);
+            const int yo = yb0 + 16 * b + row, xo = x0 + 4 * piece;
             u32x4* dst = reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo);
             if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
-                __builtin_nontemporal_store(u32x4{pend[0], pend[1], pend[2], pend[3]}, dst);
+                __builtin_nontemporal_store(v, dst);
         };
         auto step = [&](int b, Staged& cur, Staged& nxt) {
             const bool more = b + 1 < nb;
@@ -333,14 +340,7 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
             // else in the block; waiting after the stores would wait for the stores too (one in-order counter)
             if (more)
                 write_slab(b + 2, cur);
-            // The accumulator layout leaves lane (n, hgrp) with row n, pixels 4 hgrp .. 4 hgrp + 3: neighbouring lanes
-            // hold different ROWS, and the memory pipeline merges neighbouring lanes only — every lane's 16 bytes would
-            // travel as a request of its own (WRITE_SIZE read 1.30 x the bytes stored).  One lane permutation
-            // (ds_bpermute_b32, the LDS crossbar, no LDS memory) puts the four pieces of a row on four consecutive
-            // lanes: lane L gets row L >> 2, piece L & 3, and each 64-byte row segment leaves as one request.
-    #pragma unroll
-            for (int e = 0; e < 4; e++)
-                pend[e] = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((l & 3) * 16 + (l >> 2)), (int)px[e]);
+            *reinterpret_cast<u32x4*>(out_tile(b) + n * kOutPitch + 16 * wv + 4 * hgrp) = u32x4{px[0], px[1], px[2], px[3]};
             __syncthreads();
         };
         for (int b = 0; b < nb; b += 2) {
