@@ -9,7 +9,10 @@
 //                    untouched, no profiling events appended, process continues                 (:461-463)
 //   even_kernel      PerformCLGaussianBlur with kernel_size 4 -> ERROR logged, call returns
 //   log_throw        Logger::setLogFile on an unwritable path -> std::runtime_error             (RT/src/Logger.cpp:50-52)
-// Scenarios that need a device (all but log_throw) are run on the GPU box only.
+//   csv <file>       FileHandler::WriteResultsToCSV: the reference's header and row format      (RT/src/FileHandler.cpp:25-34)
+//   load_images <d>  FileHandler::LoadImages: the directory scan                                 (RT/src/FileHandler.cpp:5-14)
+// Scenarios that need a device (all but log_throw, csv, load_images) are run on the GPU box only.
+#include <FileHandler.hpp>
 #include <ProgramHandler.hpp>
 
 #include <cstdio>
@@ -30,6 +33,22 @@ int main(int argc, char** argv)
             return 0;
         }
         return 1;
+    }
+    if (what == "csv" && argc > 2) {
+        FileHandler fh;
+        std::vector<std::tuple<std::string, std::string, std::string, int, double, double, double, double, double, double,
+                               double>>
+            rows;
+        rows.emplace_back("2026-10-04 12:00:00", "a.jpg", "640x512", 100, 0.30868, 1.512, 0.05, 0.7, 0.4, 1.15, 0.000410156);
+        rows.emplace_back("2026-10-04 12:00:01", "b.jpg", "75x75", 3, 1.0, 2.0, 0.5, 0.25, 0.125, 0.875, 0.0);
+        fh.WriteResultsToCSV(argv[2], rows);
+        return 0;
+    }
+    if (what == "load_images" && argc > 2) {
+        FileHandler fh;
+        for (const auto& p : fh.LoadImages(argv[2]))
+            std::printf("%s\n", p.c_str());
+        return 0;
     }
     logger.setLogLevel(Logger::LogLevel::ERROR);
     logger.setTerminalDisplay(true);

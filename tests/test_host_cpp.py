@@ -128,3 +128,47 @@ def test_error_conventions_match_the_reference(host_built):
     assert r.returncode == 0 and "output untouched" in r.stdout and "[ERROR] Failed to write cl_mem" in r.stdout
     r = _run_err("even_kernel")
     assert r.returncode == 0 and "0 events" in r.stdout and "[ERROR] Failed when executing kernel: bad argument" in r.stdout
+
+
+REF_CSV_HEADER = ("Timestamp, Image, Resolution, Num_Iterations, avg_CPU_Time_ms, avg_OpenCL_Time_ms, "
+                  "avg_OpenCL_kernel_ms, avg_OpenCL_kernel_write_ms, avg_OpenCL_kernel_read_ms, "
+                  "avg_OpenCL_kernel_operation_ms, Error_MAE")   # RT/src/FileHandler.cpp:28, byte for byte
+
+
+def test_csv_writer_and_directory_scan_like_the_reference(host_built, tmp_path):
+    """FileHandler::WriteResultsToCSV writes the reference's file (header byte for byte, ", "-separated rows through
+    operator<< of double: RT/src/FileHandler.cpp:25-34); LoadImages scans a directory for images (:5-14).  No GPU."""
+    out = tmp_path / "results.csv"
+    r = subprocess.run([HOST_ERRORS, "csv", str(out)], capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().split("\n")
+    assert lines[0] == REF_CSV_HEADER and lines[-1] == ""
+    assert lines[1] == "2026-10-04 12:00:00, a.jpg, 640x512, 100, 0.30868, 1.512, 0.05, 0.7, 0.4, 1.15, 0.000410156"
+    assert lines[2] == "2026-10-04 12:00:01, b.jpg, 75x75, 3, 1, 2, 0.5, 0.25, 0.125, 0.875, 0"
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for name in ("b.png", "a.jpg", "notes.txt", "c.ppm"):
+        (d / name).write_bytes(b"x")
+    r = subprocess.run([HOST_ERRORS, "load_images", str(d)], capture_output=True, text=True, timeout=60, cwd=str(tmp_path))
+    assert r.returncode == 0
+    assert [os.path.basename(p) for p in r.stdout.split()] == ["a.jpg", "b.png", "c.ppm"]
+
+
+def test_host_layer_is_clean_under_address_and_undefined_sanitizers(pkg, tmp_path):
+    """host code is built with -fsanitize=address,undefined for tests.  The host sources + the error
+    scenarios that need no device, compiled with both sanitizers, run clean (leak detection off: the HIP runtime the
+    C-ABI library links keeps process-lifetime allocations)."""
+    host = os.path.join(entry.PKG_DIR, "host")
+    srcs = [os.path.join(host, "src", f) for f in sorted(os.listdir(os.path.join(host, "src"))) if f.endswith(".cpp")]
+    exe = tmp_path / "host_errors_asan"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+           "-I", os.path.join(host, "include"), "-I", os.path.join(entry.ROOT, "include"),
+           os.path.join(host, "tests", "host_errors.cpp")] + srcs + \
+          ["-L", LIBDIR, "-lmi355_imgfilter", "-Wl,-rpath," + LIBDIR, "-o", str(exe)]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    for args in (["log_throw"], ["csv", str(tmp_path / "r.csv")], ["load_images", str(tmp_path)]):
+        r = subprocess.run([str(exe)] + args, capture_output=True, text=True, timeout=120, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, (args, r.stderr[-2000:])
+        assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-2000:]
