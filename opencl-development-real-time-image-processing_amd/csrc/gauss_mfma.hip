@@ -158,10 +158,16 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         a2lo[j] = lo;
     }
 
-    // ---- staging: thread (r, qc) brings one row's quad qc of the 64 interior pixels, threads with qc < 4 one of the
-    // four halo quads of that row as well --------------------------------------------------------------------------
-    const int r = tid / kQuadsPerRow, qc = tid % kQuadsPerRow;
-    const int col_main = kHalo + 4 * qc;                             // LDS column of the main quad
+    // ---- roles.  The first half of the waves LOADS (and converts, and fills the LDS planes), the second half STORES
+    // (reads the output tile, writes the rows); every wave computes.  Loads and stores share one in-order counter per
+    // wave (vmcnt), and hipcc waits for that counter to reach zero in front of every step's loads: a wave that does
+    // both waits for its previous store each step.  (Stores redirected to an L2-resident region: +1 %; stores
+    // removed: +14 % — it is the waiting, not the DRAM traffic.)  A wave that only stores never waits at all.
+    // Loader thread (r, qs): row r of the slab, quads qs and qs + kQuadsPerRow / 2, and one halo quad when qs < 4.
+    constexpr int kLQ = kQuadsPerRow / 2;  // loader threads per row (kThreads / 2 = 16 rows x kLQ)
+    const bool is_loader = wv < kWaves / 2;  // wave-uniform
+    const int r = (tid / kLQ) & 15, qc = tid % kLQ;
+    const int col_main = kHalo + 4 * qc;                             // LDS column of the first main quad
     const int col_halo = (qc < 2) ? 4 * qc : kCols - 8 + 4 * (qc - 2);  // columns 0, 4, 72, 76
     const bool has_halo = qc < 4;
     const uint32_t* fin = reinterpret_cast<const uint32_t*>(in) + frame * (size_t)w * h;
@@ -208,13 +214,16 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         // loads are issued two blocks (2 x ~2.5 us) before their data is needed.  With one set (loads one block
         // ahead) the kernel ran at the same speed with its arithmetic removed: it was bound by load latency.
         struct Staged {
-            u32x4 main, halo;
+            u32x4 main, main2, halo;
         };
         Staged stA, stB;
         auto load_slab = [&](int s, Staged& st) {  // slab s = image rows yb0 - 8 + 16 s .. + 15
+            if (!is_loader)
+                return;
             const int y = clampi(yb0 - kHalo + 16 * s + r, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)
             const uint32_t* rowp = fin + (size_t)y * w;
             st.main = load_quad(rowp, x0 + 4 * qc);
+            st.main2 = load_quad(rowp, x0 + 4 * (qc + kLQ));
             if (has_halo)
                 st.halo = load_quad(rowp, x0 - kHalo + col_halo);
         };
@@ -223,9 +232,12 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         // output alpha is the constant — the block skips the alpha channel, a quarter of its matrix and vector work.
         // (Every frame the reference hands its Controller went through cvtColor(BGR2RGBA): RT/src/ProgramHandler.cpp:127.)
         auto write_slab = [&](int s, const Staged& st) {
+            if (!is_loader)
+                return;
             const int slot = s % 3;
             store_quad(slot, col_main, st.main);
-            uint32_t a = st.main[0] & st.main[1] & st.main[2] & st.main[3];
+            store_quad(slot, col_main + 4 * kLQ, st.main2);
+            uint32_t a = st.main[0] & st.main[1] & st.main[2] & st.main[3] & st.main2[0] & st.main2[1] & st.main2[2] & st.main2[3];
             if (has_halo) {
                 store_quad(slot, col_halo, st.halo);
                 a &= st.halo[0] & st.halo[1] & st.halo[2] & st.halo[3];
@@ -258,12 +270,18 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         // is overwritten at the end of step b + 2 — two barriers later.
         auto out_tile = [&](int b) { return otile + (b & 1) * (16 * kOutPitch); };
         auto store_block = [&](int b) {
-            const int row = tid / (kTX / 4), piece = tid % (kTX / 4);
-            const u32x4 v = *reinterpret_cast<const u32x4*>(out_tile(b) + row * kOutPitch + 4 * piece);
-            const int yo = yb0 + 16 * b + row, xo = x0 + 4 * piece;
-            u32x4* dst = reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo);
-            if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
-                __builtin_nontemporal_store(v, dst);
+            if (is_loader)
+                return;
+    #pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int j = (tid - kThreads / 2) + half * (kThreads / 2);  // quad of the 16 x (kTX / 4) tile
+                const int row = j / (kTX / 4), piece = j % (kTX / 4);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(out_tile(b) + row * kOutPitch + 4 * piece);
+                const int yo = yb0 + 16 * b + row, xo = x0 + 4 * piece;
+                u32x4* dst = reinterpret_cast<u32x4*>(fout + (size_t)yo * w + xo);
+                if (yo < h && xo < w)  // w % 4 == 0 and xo % 4 == 0: the lane's four pixels are inside together
+                    __builtin_nontemporal_store(v, dst);
+            }
         };
         auto step = [&](int b, Staged& cur, Staged& nxt) {
             const bool more = b + 1 < nb;
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
             const int f0 = (b % 3) * kWaves, f1 = ((b + 1) % 3) * kWaves;
             uint32_t any_clear = 0u;
     #pragma unroll
-            for (int v = 0; v < kWaves; v++)
+            for (int v = 0; v < kWaves / 2; v++)  // the loader waves
                 any_clear |= clear_flag[f0 + v] | clear_flag[f1 + v];
             const bool opaque = __builtin_amdgcn_readfirstlane(any_clear) == 0;
     #pragma unroll
