@@ -7,7 +7,7 @@ namespace mi355 {
 
 namespace {
 
-enum class GaussKernel { Tile, Slide, Wide, Mfma };
+enum class GaussKernel { Tile, Slide, Wide, Mfma, Exact };
 
 // AUTO: which k the matrix-core kernel takes over from the register-resident VALU kernels.  Its cost does not
 // depend on k (one K = 32 matrix instruction covers any radius <= 8), theirs grows with k.  Same box, 64 x 4K frames
@@ -17,7 +17,10 @@ constexpr int kMfmaAutoMinK = 11;
 GaussKernel choose(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
                    bool exact, int impl)
 {
-    // EXACT arithmetic exists only in the tiled kernel
+    // EXACT arithmetic: the sliding-window exact-by-exception kernel where it applies (a table it cannot take —
+    // non-separable, asymmetric factor — arrives here with exact = true as well), the tiled kernel otherwise
+    if (exact && impl != MI355_IMPL_TILE && gauss_exact_supported(d_in, d_out, w, h, coef))
+        return GaussKernel::Exact;
     if (exact || impl == MI355_IMPL_TILE)
         return GaussKernel::Tile;
     const bool mfma_ok = gauss_mfma_supported(d_in, d_out, w, h, coef);
@@ -50,6 +53,7 @@ hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
 {
     switch (choose(d_in, d_out, w, h, nframes, coef, exact, impl)) {
     case GaussKernel::Mfma: return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
+    case GaussKernel::Exact: return launch_gauss_exact(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Slide: return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     case GaussKernel::Wide: return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     default: return launch_gauss_tile(stream, d_in, d_out, w, h, nframes, coef, exact);

@@ -258,7 +258,6 @@ __global__ __launch_bounds__(kThreads) void gauss_mfma_kernel(const uint8_t* __r
         const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) _Float16*)lds;
         // per-lane offsets of the two transposed reads of a D1 tile (elements): row 4 hgrp + q, column 4 p
         const int tr_off = (4 * hgrp + q) * kPitch + 4 * p + 16 * wv;
-        const int xt = x0 + 16 * wv;
 
         // one block; `cur` holds slab b + 2 (loaded during block b - 1), `nxt` receives slab b + 3
         // Output path.  The accumulator layout leaves lane (n, hgrp) of wave v with row n, pixels 16 v + 4 hgrp .. + 3:

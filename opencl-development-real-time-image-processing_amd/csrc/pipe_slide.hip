@@ -37,6 +37,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "slide_common.hpp"
+#include "exact_common.hpp"
 
 namespace mi355 {
 
@@ -50,41 +51,6 @@ struct PTables {
     float w2[K * K];  // the reference's 2-D table, row-major [ky][kx] — read only by the exact chain
     float delta;      // |S - S_cpu| bound
 };
-
-__device__ __forceinline__ float dppl(float v)  // lane l <- lane l-1
-{
-    return __builtin_bit_cast(float,
-                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
-}
-
-__device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
-{
-    return __builtin_bit_cast(float,
-                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
-}
-
-// The CPU path's own sum for pixel J of every lane (GaussianBlur.cpp:243-256: ky outer, kx inner, float multiply
-// then float add, starting from 0), from the ring of gray rows: the window's arrival rows sit in slots
-// (u + 1 + t) % K, t = 0 .. K-1, and the rows are visited in IMAGE order, top to bottom — arrival order for a band
-// walking down, the reverse for a band walking up (UP).  u is a constant after unrolling, so every register index
-// is static.  Runs under a wave-uniform branch: EXEC is full, the DPP reads see every lane.
-template <int K, int J, bool UP>
-__device__ __forceinline__ float exact_sum(const float (&g)[K][4], int u, const float* __restrict__ w2)
-{
-    constexpr int R = K / 2;
-    float sum = 0.0f;
-#pragma unroll
-    for (int ky = 0; ky < K; ky++) {
-        const float* r = g[(u + 1 + (UP ? K - 1 - ky : ky)) % K];
-#pragma unroll
-        for (int kx = 0; kx < K; kx++) {
-            const int col = J - R + kx;
-            const float val = (col < 0) ? dppl(r[4 + col]) : ((col > 3) ? dppr(r[col - 4]) : r[col]);
-            sum = sum + val * w2[ky * K + kx];  // -ffp-contract=off: v_mul_f32 then v_add_f32
-        }
-    }
-    return sum;
-}
 
 // RAGGED = width % 4 != 0 or unaligned buffers (see gauss_slide.hip / sobel_slide.hip): unaligned 16-byte row
 // accesses in interior strips, per-pixel clamped loads and per-byte stores in the two edge strips, and the
@@ -358,49 +324,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
             }
         }
     }
-}
-
-// u(x) = half an ulp of a float of magnitude <= x
-double half_ulp(double x)
-{
-    if (!(x > 0.0))
-        return 0.0;
-    int e = 0;
-    std::frexp(x, &e);  // x = m * 2^e, m in [0.5, 1)  ->  ulp = 2^(e - 24)
-    return std::ldexp(1.0, e - 25);
-}
-
-// |S - S_cpu| <= delta for every window of bytes, where S is the kernel's separable pair-form evaluation with w1 and
-// S_cpu the CPU path's k*k-term float sum with w2.  Everything is non-negative (checked by the caller), so partial
-// sums never exceed the final ones.
-template <int K>
-double delta_bound(const float* w1, const float* w2)
-{
-    constexpr int R = K / 2;
-    double sum2 = 0.0, max2 = 0.0, sum1 = 0.0, mismatch = 0.0;
-    for (int i = 0; i < K * K; i++) {
-        sum2 += (double)w2[i];
-        max2 = std::fmax(max2, (double)w2[i]);
-    }
-    for (int i = 0; i < K; i++)
-        sum1 += (double)w1[i];
-    for (int i = 0; i < K; i++)
-        for (int j = 0; j < K; j++)
-            mismatch += std::fabs((double)w1[i] * (double)w1[j] - (double)w2[i * K + j]);
-    // CPU path: k*k products (each rounded), k*k additions (each rounded; partial sums <= 255 * sum2)
-    const double e_cpu = K * K * half_ulp(255.0 * max2) + K * K * half_ulp(255.0 * sum2);
-    // kernel, vertical: R + 1 multiply-adds on values <= 255 * sum1 (the integer pair sums are exact)
-    const double tv = 255.0 * sum1;
-    const double e_v = (R + 1) * half_ulp(tv);
-    // kernel, horizontal: R pair sums of vertical results (<= 2 tv each, weighted), R + 1 multiply-adds on values
-    // <= 255 * sum1^2, plus the vertical error carried through weights that sum to sum1
-    double e_pairs = 0.0;
-    for (int d = 1; d <= R; d++)
-        e_pairs += (double)w1[R - d] * half_ulp(2.0 * tv);
-    // (+1: the centre tap carries + delta, one more rounding of a value of that size)
-    const double e_h = e_v * sum1 + e_pairs + (R + 2) * half_ulp(255.0 * sum1 * sum1 + 0.01);
-    // every term above is a worst case already; the margin only covers the double arithmetic of this function
-    return 1.02 * (e_cpu + e_h + 255.0 * mismatch) + 1e-7;
 }
 
 template <int R>

@@ -374,3 +374,48 @@ def test_image2d_mode_fixture(ctx, pkg, oracle, fixture_rgba):
     assert np.abs(got.astype(int) - oracle.gray_rgba_1ch(fixture_rgba).astype(int)).max() <= 1
     got, _ = ctx.image2d(pkg.FILTER_GAUSS, fixture_rgba, 5, 1.5)
     assert np.array_equal(got, oracle.image2d_gauss(fixture_rgba, 5, 1.5))
+
+
+# ---- EXACT mode at sliding-window speed (csrc/gauss_exact.hip) -----------------------------------------------------
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5)])
+@pytest.mark.parametrize("h,w", [(1, 4), (2, 8), (7, 12), (40, 252), (33, 248), (131, 500), (300, 1920), (5, 3840)])
+def test_exact_mode_sliding_kernel(ctx, pkg, oracle, k, sigma, h, w):
+    """MI355_GAUSS_EXACT on 4-pixel-multiple widths runs the exact-by-exception sliding kernel: bit-identical to the CPU
+    path (src/GaussianBlur/GaussianBlur.cpp:234-261) and to the tiled EXACT kernel, on noise, opaque and flat frames."""
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    try:
+        for case in ("noise", "opaque", "one_hole", "flat"):
+            if case == "noise":
+                img = rand_rgba(h, w, seed=h + w + k, alpha=None)
+            elif case == "flat":
+                img = np.full((h, w, 4), 255, np.uint8)
+                img[:, w // 2:, :3] = 17
+            else:
+                img = oracle.synth_rgba(w, h, 1, first_frame=k, mode=1)[0].copy()   # A = 255
+                if case == "one_hole":
+                    img[h // 2, (w * 3) // 4, 3] = 9
+            ref = oracle.gauss_rgba(img, k, sigma, threads=8)
+            assert np.array_equal(ctx.gauss(img, k, sigma), ref), case
+            ctx.set_impl(pkg.IMPL_TILE)
+            assert np.array_equal(ctx.gauss(img, k, sigma), ref), case
+            ctx.set_impl(pkg.IMPL_AUTO)
+    finally:
+        ctx.set_impl(pkg.IMPL_AUTO)
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+
+
+def test_exact_mode_batches_and_full_frames(ctx, pkg, oracle):
+    ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+    try:
+        frames = oracle.synth_rgba(1000, 300, 4, first_frame=1, mode=0).copy()
+        frames[2, 150:160, 400:420, 3] = 0          # a non-opaque patch inside one frame of the batch
+        got = ctx.gauss(frames, 5, 1.5)
+        for f in range(4):
+            assert np.array_equal(got[f], oracle.gauss_rgba(frames[f], 5, 1.5, threads=8)), f
+        for mode in (0, 1):
+            frame = oracle.synth_rgba(W4K, H4K, 1, first_frame=3, mode=mode)[0]
+            assert np.array_equal(ctx.gauss(frame, 5, 1.5), oracle.gauss_rgba(frame, 5, 1.5, threads=_threads(oracle)))
+        noisy = rand_rgba(1080, 1920, seed=21, alpha=None)
+        assert np.array_equal(ctx.gauss(noisy, 3, 0.8), oracle.gauss_rgba(noisy, 3, 0.8, threads=_threads(oracle)))
+    finally:
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
