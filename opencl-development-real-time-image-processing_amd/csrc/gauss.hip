@@ -52,7 +52,12 @@ hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
                         int nframes, const GaussCoef& coef, bool exact, int impl, uint32_t* d_flags)
 {
     switch (choose(d_in, d_out, w, h, nframes, coef, exact, impl)) {
-    case GaussKernel::Mfma: return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
+    case GaussKernel::Mfma:
+        // the register-operand skeleton (gauss_mfma_reg.hip) is the faster one; the LDS-staged kernel stays as its
+        // A/B partner (tuning build: MI355_MFMA_LDS=1) and for frames of 2 GiB and more
+        if (!tune_env("MI355_MFMA_LDS") && gauss_mfma_reg_supported(d_in, d_out, w, h, coef))
+            return launch_gauss_mfma_reg(stream, d_in, d_out, w, h, nframes, coef);
+        return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Exact: return launch_gauss_exact(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Slide: return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     case GaussKernel::Wide: return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
