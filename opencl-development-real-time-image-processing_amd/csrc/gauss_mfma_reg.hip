@@ -172,18 +172,30 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
             to_matrix_lanes(st);
             const uint32_t a = st.lo[0] & st.lo[1] & st.lo[2] & st.lo[3] & st.hi[0] & st.hi[1] & st.hi[2] & st.hi[3];
             t.clear = __builtin_amdgcn_ballot_w64(a < 0xFF000000u) != 0;
+            // pixel pairs deinterleaved once: rb[i] = (R0, R1, B0, B1), ga[i] = (G0, G1, A0, A1) of pixels 2i, 2i + 1
+            uint32_t rb[4], ga[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t p0 = (i < 2) ? st.lo[2 * i] : st.hi[2 * i - 4], p1 = (i < 2) ? st.lo[2 * i + 1] : st.hi[2 * i - 3];
+                rb[i] = __builtin_amdgcn_perm(p1, p0, 0x06020400u);
+                ga[i] = __builtin_amdgcn_perm(p1, p0, 0x07030501u);
+            }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 if (c == 3 && !t.clear) {  // wave-uniform
                     t.hi[1][2] = t.hi[1][3] = t.lo[1][2] = t.lo[1][3] = 0u;
                     continue;
                 }
-                const uint32_t sel = 0x0C000C00u | (uint32_t)c | ((uint32_t)(4 + c) << 16);  // (0, S0.byte c, 0, S1.byte c)
-                uint32_t d[4] = {__builtin_amdgcn_perm(st.lo[1], st.lo[0], sel), __builtin_amdgcn_perm(st.lo[3], st.lo[2], sel),
-                                 __builtin_amdgcn_perm(st.hi[1], st.hi[0], sel), __builtin_amdgcn_perm(st.hi[3], st.hi[2], sel)};
+                // channel c of pixel pair i sits in bytes (c >> 1) * 2, (c >> 1) * 2 + 1 of rb[i] (c even) / ga[i] (c odd);
+                // the exponent byte comes from the constant: one v_perm_b32 per operand dword
+                const uint32_t sel = (c >> 1) ? 0x04030402u : 0x04010400u;  // (S1.b, 0x64, S1.b', 0x64), S0 = 0x64646464
+                uint32_t d[4];
 #pragma unroll
-                for (int i = 0; i < 4; i++)
-                    d[i] = (c == 3) ? 0x64FF64FFu - d[i] : (d[i] | 0x64006400u);
+                for (int i = 0; i < 4; i++) {
+                    d[i] = __builtin_amdgcn_perm(0x64646464u, (c & 1) ? ga[i] : rb[i], sel);
+                    if (c == 3)
+                        d[i] ^= 0x00FF00FFu;  // 255 - A
+                }
                 const h8 a1 = __builtin_bit_cast(h8, u32x4{d[0], d[1], d[2], d[3]});
                 f4 acc = {plane_bias, plane_bias, plane_bias, plane_bias};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1hi, acc, 0, 0, 0);
@@ -311,9 +323,10 @@ hipError_t launch_gauss_mfma_reg(hipStream_t stream, const uint8_t* d_in, uint8_
     RPlan plan;
     plan.nstrips = (w + kStripR - 1) / kStripR;
     plan.nblocks = (h + 15) / 16;
-    // ~15 blocks (240 rows) per band: one extra 16-row tile per band is 6.7 % extra reads and pass-1 work; launches
-    // too small to fill the chip are cut finer
-    int bpb = 15;
+    // Tall bands: a band pays one extra 16-row tile of reads and pass-1 work.  Same box, 256 x 4K frames, k = 17:
+    // 15 blocks per band 4.91 TB/s, 30: 5.05, 45: 5.13, 68: 5.19, 135 (the whole height): 5.20; 64 frames and 1080p
+    // peak at 68.  Launches too small to fill the chip are cut finer.
+    int bpb = 68;
     if (const char* e = tune_env("MI355_MFMA_BPB"))
         bpb = atoi(e);
     while (bpb > 2 && (size_t)plan.nstrips * ((plan.nblocks + bpb - 1) / bpb) * nframes < 2048)
