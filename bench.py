@@ -69,7 +69,7 @@ def parse(argv=None):
     p.add_argument("--k", type=int, default=5)
     p.add_argument("--sigma", type=float, default=1.5)
     p.add_argument("--mode", default="fast", choices=["fast", "exact"])
-    p.add_argument("--impl", default="auto", choices=["auto", "tile", "mfma"], help="kernel selection "
+    p.add_argument("--impl", default="auto", choices=["auto", "tile", "mfma", "valu"], help="kernel selection "
                    "(mi355_ctx_set_impl): auto = the library's own choice")
     p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise")
     p.add_argument("--random-alpha", action="store_true", help="overwrite the frames' alpha (255 by definition "
@@ -237,7 +237,7 @@ def main(argv=None):
     stream = torch.cuda.current_stream(dev)
     ctx = pkg.Context(local_rank, stream=stream.cuda_stream)
     ctx.set_gauss_mode(pkg.GAUSS_EXACT if args.mode == "exact" else pkg.GAUSS_FAST)
-    ctx.set_impl({"auto": pkg.IMPL_AUTO, "tile": pkg.IMPL_TILE, "mfma": pkg.IMPL_MFMA}[args.impl])
+    ctx.set_impl({"auto": pkg.IMPL_AUTO, "tile": pkg.IMPL_TILE, "mfma": pkg.IMPL_MFMA, "valu": pkg.IMPL_VALU}[args.impl])
 
     w, h = args.width, args.height
     first_frame, F = shard_range(rank, world, args.frames, args.total_frames)

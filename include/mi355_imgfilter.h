@@ -64,17 +64,22 @@ const char* mi355_strerror(int code);
 
 int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
 
-/* Kernel selection (a tuning / test knob; results are bit-identical):
- *   AUTO — the register-resident sliding-window kernels when they apply (any width; Gaussian: FAST mode and
- *          k in {3,5,7,9} or, with an even width, {11,13,15,17}; pipeline: FAST mode, k in {3,5,7}, w >= 4,
- *          h >= 2); the LDS-tiled kernels otherwise.
- *   TILE — always the LDS-tiled kernels. */
+/* Kernel selection (a tuning / test knob):
+ *   AUTO — the fastest kernel that applies.  Gaussian, FAST mode: the register-resident sliding-window kernels for
+ *          k in {3,5,7} (any width); the matrix-core kernel for odd 9 <= k <= 17 when width % 4 == 0, width >= 64,
+ *          the launch has >= 2^16 pixels and the device buffers are 16-byte aligned, the VALU kernels otherwise
+ *          (k = 9 any width; k in {11,13,15,17} with an even width); the LDS-tiled kernel for everything else.
+ *          EXACT mode: the exact-by-exception sliding kernel for k in {3,5} and width % 4 == 0, the tiled kernel
+ *          otherwise.  Pipeline: k in {3,5,7}, w >= 4, h >= 2 sliding, tiled otherwise.
+ *   TILE — always the LDS-tiled kernels.
+ *   VALU — as AUTO but never the matrix cores.  TILE and VALU give identical bits. */
 #define MI355_IMPL_AUTO 0
 #define MI355_IMPL_TILE 1
-/*   MFMA — the Gaussian on the matrix cores (csrc/gauss_mfma.hip) wherever it applies (FAST mode, odd k <= 17,
+/*   MFMA — the Gaussian on the matrix cores (csrc/gauss_mfma_reg.hip) wherever it applies (FAST mode, odd k <= 17,
  *          width % 4 == 0, 16-byte aligned device buffers); AUTO elsewhere.  Within 1 LSB of the CPU path like every
  *          FAST kernel, but not bit-identical to the VALU kernels (other rounding). */
 #define MI355_IMPL_MFMA 2
+#define MI355_IMPL_VALU 3
 int mi355_ctx_set_impl(mi355_ctx* ctx, int impl);
 
 /* Input pixel format of the HOST-buffer calls (mi355_*_rgba8, mi355_filter_batched, mi355_filter_stream):

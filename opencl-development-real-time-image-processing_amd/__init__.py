@@ -17,6 +17,7 @@ from .imgfilter import (  # noqa: F401
     INPUT_BGR,
     INPUT_RGBA,
     IMPL_TILE,
+    IMPL_VALU,
     Context,
     Mi355Error,
     build_library,

@@ -568,7 +568,7 @@ MI355_API int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode)
 
 MI355_API int mi355_ctx_set_impl(mi355_ctx* ctx, int impl)
 {
-    if (!ctx || (impl != MI355_IMPL_AUTO && impl != MI355_IMPL_TILE && impl != MI355_IMPL_MFMA))
+    if (!ctx || impl < MI355_IMPL_AUTO || impl > MI355_IMPL_VALU)
         return MI355_ERR_BAD_ARG;
     ctx->impl = impl;
     return MI355_OK;

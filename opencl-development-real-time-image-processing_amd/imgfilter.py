@@ -22,7 +22,7 @@ _HEADER = os.path.join(_ROOT, "include", "mi355_imgfilter.h")
 FILTER_GRAY, FILTER_GRAY1, FILTER_GAUSS, FILTER_SOBEL, FILTER_PIPELINE = 0, 1, 2, 3, 4
 GAUSS_FAST, GAUSS_EXACT = 0, 1
 INPUT_RGBA, INPUT_BGR = 0, 1
-IMPL_AUTO, IMPL_TILE, IMPL_MFMA = 0, 1, 2
+IMPL_AUTO, IMPL_TILE, IMPL_MFMA, IMPL_VALU = 0, 1, 2, 3
 OUT_BPP = {FILTER_GRAY: 4, FILTER_GRAY1: 1, FILTER_GAUSS: 4, FILTER_SOBEL: 1, FILTER_PIPELINE: 1}
 
 _u8p = ctypes.POINTER(ctypes.c_uint8)

@@ -1,4 +1,5 @@
-"""GPU suite (-m gpu): the matrix-core Gaussian (csrc/gauss_mfma.hip, MI355_IMPL_MFMA) against the oracle.
+"""GPU suite (-m gpu): the matrix-core Gaussian (csrc/gauss_mfma_reg.hip, MI355_IMPL_MFMA; its LDS-staged A/B
+partner csrc/gauss_mfma.hip through the tuning build) against the oracle.
 
 Contract: FAST arithmetic, |d| <= 1 LSB per channel against the CPU path (src/GaussianBlur/GaussianBlur.cpp:234-261)
 on every shape; the fp16 hi + lo splits keep the error of the sums near 1e-4, so the share of bytes that differ at
@@ -74,3 +75,45 @@ def test_mfma_falls_back_where_it_does_not_apply(mfma, pkg, oracle):
     mfma.set_gauss_mode(pkg.GAUSS_EXACT)
     assert np.array_equal(mfma.gauss(img, 17, 6.0), oracle.gauss_rgba(img, 17, 6.0))
     mfma.set_gauss_mode(pkg.GAUSS_FAST)
+
+
+_PARTNER_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import __graft_entry__ as entry
+from conftest import rand_rgba
+pkg = entry.load_package(); oracle = entry.load_oracle()
+worst = 0
+with pkg.Context(0) as ctx:
+    ctx.set_impl(pkg.IMPL_MFMA)
+    for (h, w, k, s, a) in [(16, 64, 17, 6.0, None), (33, 68, 5, 1.5, None), (200, 640, 11, 3.0, 255), (75, 252, 9, 2.5, None),
+                            (1100, 320, 17, 6.0, 255), (2300, 128, 13, 3.3, None)]:
+        img = rand_rgba(h, w, seed=h + w + k, alpha=a)
+        if a == 255:
+            img[h // 2, w // 3, 3] = 7
+        d = np.abs(ctx.gauss(img, k, s).astype(np.int16) - oracle.gauss_rgba(img, k, s, threads=8).astype(np.int16))
+        worst = max(worst, int(d.max()))
+        assert (d != 0).mean() < 0.005 or d.size < 4096, (h, w, k)
+print(worst)
+"""
+
+
+def test_lds_staged_partner_and_band_heights():
+    """The tuning build keeps two knobs of the matrix-core path reachable: MI355_MFMA_LDS=1 runs the LDS-staged kernel
+    (gauss_mfma.hip, round 2's first version, the A/B partner of tools/mfma_reg_ab.sh), MI355_MFMA_BPB sets the band
+    height of gauss_mfma_reg.hip (1 block per band: every block pays a halo tile; 3: ragged last band).  Each within
+    1 LSB of the oracle on shapes with edges, several bands (2300 rows > 68 blocks), opaque frames with one hole."""
+    import os
+    import subprocess
+    import sys
+    import __graft_entry__ as entry
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune_lib = os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so")
+    assert os.path.exists(tune_lib), "run __graft_entry__.build()"
+    for knobs in ({"MI355_MFMA_LDS": "1"}, {"MI355_MFMA_BPB": "1"}, {"MI355_MFMA_BPB": "3"}):
+        env = dict(os.environ, MI355_IMGFILTER_LIB=tune_lib, **knobs)
+        out = subprocess.run([sys.executable, "-c", _PARTNER_SCRIPT, root], env=env, capture_output=True, text=True,
+                             timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert int(out.stdout.strip().splitlines()[-1]) <= 1, (knobs, out.stdout)
