@@ -11,10 +11,10 @@ enum class GaussKernel { Tile, Slide, Wide, Mfma, Exact };
 
 // AUTO: which k the matrix-core kernel takes over from the register-resident VALU kernels.  Its cost does not
 // depend on k (one K = 32 matrix instruction covers any radius <= 8), theirs grows with k.  Same box, 256 x 4K frames,
-// VALU / matrix cores (tools/k79_ab.sh): k = 7 opaque 5.05 / 4.98 TB/s, alpha noise 4.20 / 4.60; k = 9 opaque 4.39 /
-// 4.95, alpha noise 3.42 / 4.61, one frame 2.22 / 3.35; k = 11 2.85 / 5.0; k = 17 2.05 / 5.0.  k = 7 stays with the VALU
-// kernel (a tie on opaque frames, and it gives the tiled kernel's bits).
-constexpr int kMfmaAutoMinK = 9;
+// VALU / matrix cores (profiles/r02_kernel_table.txt, tools/k79_ab.sh): k = 5 opaque 5.91 / 5.07 TB/s, alpha noise
+// 5.16 / 4.5; k = 7 opaque 4.96 / 5.21 (5.05 / 4.98 on another box), alpha noise 4.20 / 4.60; k = 9 opaque 4.32 / 5.16,
+// alpha noise 3.42 / 4.61, one frame 2.22 / 3.35; k = 11 2.83 / 5.05; k = 17 2.01 / 5.04.
+constexpr int kMfmaAutoMinK = 7;
 
 GaussKernel choose(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int nframes, const GaussCoef& coef,
                    bool exact, int impl)

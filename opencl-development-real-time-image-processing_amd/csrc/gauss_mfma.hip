@@ -1,5 +1,9 @@
 // gauss_mfma.hip — separable Gaussian blur of RGBA8 frames on the matrix cores, any odd k <= 17 (the reference
 // application's own default is k = 17, sigma = 6: include/ProgramHandler.hpp:9), width % 4 == 0.  gfx950 only.
+// The LDS-STAGED version: the first matrix-core kernel of this library.  gauss_mfma_reg.hip (operands loaded straight
+// into the matrix layout, horizontal pass first) is 15-20 % faster and is what MI355_IMPL_MFMA / AUTO launch; this one
+// stays as its A/B partner (tuning build, MI355_MFMA_LDS=1: tools/mfma_reg_ab.sh, tests/test_gpu_mfma.py) and serves
+// frames of 2 GiB and more, which the other kernel's 32-bit row offsets exclude.
 //
 // Why matrix cores for a stencil: at k = 17 the separable blur costs 2 * 17 * 4 = 136 multiply-adds per pixel; the
 // register-resident VALU kernel (gauss_wide.hip) is FP32-issue-bound at 2.1 TB/s (26 % of the HBM roofline).  Each

@@ -1,24 +1,36 @@
-// gauss_mfma_reg.hip — separable Gaussian blur of RGBA8 frames on the matrix cores WITHOUT local memory: every
-// operand of both passes is born in the register layout the matrix instruction wants.  Any odd k <= 17, width % 4 == 0.
-// gfx950 only.  Same arithmetic and the same contract as gauss_mfma.hip (within 1 LSB per channel of the CPU path,
-// src/GaussianBlur/GaussianBlur.cpp:234-261); a different skeleton.
+// gauss_mfma_reg.hip — separable Gaussian blur of RGBA8 frames on the matrix cores, every matrix operand born in the
+// register layout the instruction wants (no LDS staging of the input).  Any odd k <= 17 (the reference application's
+// own default is k = 17, sigma = 6: include/ProgramHandler.hpp:9), width % 4 == 0.  gfx950 only.  Same arithmetic and
+// contract as gauss_mfma.hip (within 1 LSB per channel of the CPU path, src/GaussianBlur/GaussianBlur.cpp:234-261;
+// fp16 hi + lo splits of weights and intermediate, everything scaled by 256, see there); a different skeleton.
 //
 // gauss_mfma.hip stages fp16 planes in LDS (vertical pass first, hardware-transposed reads) and is bound by its
 // workgroup-synchronous chain — load, convert, LDS, barrier, transposed reads, matrix chain, output tile, barrier —
 // at 4.0-4.36 TB/s whatever is removed from it.  Here the HORIZONTAL pass comes first:
 //   pass 1  H[y][x'] = sum_x X[y][x] * Th[x][x']       A = X: lane (m, g) of v_mfma_f32_16x16x32_f16 supplies row m,
 //           k = 8g .. 8g+7 — EIGHT CONSECUTIVE PIXELS OF ONE ROW, which is what a 32-byte global load returns.  The
-//           lane splits its 8 RGBA pixels into four channel operands (v_perm_b32 + v_or_b32 per pair: a byte under the
-//           exponent byte 0x64 is the fp16 number 1024 + b); B = banded weights, constant registers.
+//           lane splits its 8 RGBA pixels into four channel operands (pixel pairs deinterleaved once, then one
+//           v_perm_b32 per operand dword: a byte under the exponent byte 0x64 is the fp16 number 1024 + b; the 1024s
+//           are cancelled by the accumulator's initial value); B = banded weights, constant registers.
 //   pass 2  Z[x'][y'] = sum_y H^T[x'][y] * Tv^T[y][y']  the accumulator of pass 1 has x' on the lanes and 4 rows in the
 //           registers: two vertically adjacent 16-row tiles of H (this step's and the previous step's, kept in
 //           registers as fp16 hi + lo) ARE the A operand of pass 2 (8 k-slots = rows 4g..4g+3 of either tile; the k
 //           order is baked into the constant B operand).  Z leaves row y' on the lanes and 4 consecutive pixels in the
-//           registers: one 16-byte store per lane.
-// So a WAVE owns a column of 16 output pixels and walks down a band of 16-row tiles, on its own: no LDS, no barrier,
-// loads two tiles ahead in registers — the skeleton of the sliding-window kernels.  Each H tile is computed once and
-// used by two output blocks; the 32-pixel input window of a 16-pixel column means every input pixel is loaded by two
-// waves (the four waves of a workgroup own adjacent columns: the second read is an L1/L2 hit).
+//           registers.
+// A WAVE owns a column of 16 output pixels and walks down a band of 16-row tiles with its input two tiles ahead in
+// registers; each H tile is computed once and used by two output blocks; the 32-pixel input window of a 16-pixel
+// column means every input pixel is loaded by two waves (HBM traffic stays 1.001 x algorithmic: the second read
+// hits a cache).  What the memory system needed (same-box ladder, 256 x 4K frames, k = 17):
+//   * loads issued in the matrix arrangement (adjacent lanes = adjacent ROWS): every lane its own cache line, 3.35 TB/s
+//     -> issued coalesced (lane 4r + p reads piece p of row r) and moved to the matrix arrangement with
+//     ds_bpermute_b32: 3.94;
+//   * stores from the matrix arrangement are 64-byte pieces over 16 rows: 4.1 TB/s with them, 6.4 without, and the
+//     matrix work was not the limit (4.0 with it removed) -> the four waves of a workgroup own adjacent columns, so a
+//     block goes through an LDS tile and each wave stores 4 whole rows x 256 contiguous bytes; one barrier per block:
+//     5.0 (the LDS-staged kernel on that box: 4.3);
+//   * 68 blocks per band instead of 15: 5.2.
+//   Tried and dropped: hand-issued loads with a hand-placed s_waitcnt vmcnt(2) (hipcc drains the counter at the top
+//   of every step; counting by hand was 3 % SLOWER); 5 waves per SIMD (spills).
 #include <type_traits>
 
 #include "common.hpp"
@@ -138,8 +150,7 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         // Loads are issued in the COALESCED arrangement — lane 4r + p reads piece p of row r, four adjacent lanes one
         // 128-byte line — and moved to the matrix arrangement (lane r + 16 p) by ds_bpermute_b32 when the tile is
-        // consumed.  Loading in the matrix arrangement directly (adjacent lanes = adjacent ROWS) made every lane its
-        // own cache-line access: 3.35 TB/s, the texture path saturated.
+        // consumed.
         const int lr = l >> 2, lp = l & 3;
         auto load_tile = [&](int j, Staged& st) __attribute__((always_inline)) {  // tile j = image rows yb0 - 8 + 16 j .. + 15
             const int y = clampi(yb0 - 8 + 16 * j + lr, 0, h - 1);  // clamp-to-edge rows (GaussianBlur.cpp:241)

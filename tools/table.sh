@@ -32,7 +32,17 @@ row --filter gauss --width 1920 --height 1080 --frames 1
 row --filter gauss --k 17 --sigma 6 --width 1920 --height 1080 --frames 256
 # config 5, N = 1 leg: 512 x 4K through the fused pipeline
 row --filter pipeline --total-frames 512
-# the matrix-core Gaussian forced at every k (AUTO takes it from k = 11)
+# the matrix-core Gaussian forced at small k, and the VALU kernels forced where AUTO (k >= 9) no longer takes them
 row --filter gauss --k 5 --frames 64 --impl mfma
-row --filter gauss --k 9 --sigma 2.5 --frames 64 --impl mfma
+row --filter gauss --k 7 --sigma 2.0 --impl mfma
+row --filter gauss --k 9 --sigma 2.5 --impl valu
+row --filter gauss --k 11 --sigma 3.0 --frames 64 --impl valu
+row --filter gauss --k 17 --sigma 6 --frames 64 --impl valu
 row --filter gauss --k 17 --sigma 6 --frames 256
+row --filter gauss --k 17 --sigma 6 --frames 256 --random-alpha
+# EXACT mode (bit-identical to the CPU path): exact-by-exception sliding kernel (k = 3, 5), tiled kernel (k >= 7)
+row --filter gauss --mode exact --k 3 --sigma 0.8
+row --filter gauss --mode exact
+row --filter gauss --mode exact --random-alpha
+row --filter gauss --mode exact --frames 64 --impl tile
+row --filter gauss --mode exact --k 7 --sigma 2.0 --frames 64
