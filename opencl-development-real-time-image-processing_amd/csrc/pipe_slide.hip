@@ -287,7 +287,12 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                             const float gy2 = __builtin_fmaf(2.0f, cd[2], cd[1]) + cd[3];
                             const float gy3 = __builtin_fmaf(2.0f, cd[3], cd[2]) + cdr;
                             const float gxs[4] = {gx0, gx1, gx2, gx3}, gys[4] = {gy0, gy1, gy2, gy3};
-                            const uint32_t r = sobel_mag_quad(gxs, gys);
+                            uint32_t r = sobel_mag_quad(gxs, gys);
+                            // computed by all 64 lanes, BEFORE the store's lane mask: hipcc otherwise sinks the stencil
+                            // into the masked region and keeps the four lane shifts outside it as separate
+                            // v_mov_b32_dpp (a DPP read under a partial EXEC sees zeros); here three of them fold into
+                            // their consumers.  (3 of 160 instructions per row: +0.2 %, within noise.)
+                            asm volatile("" : "+v"(r));
                             if (stores) {
                                 const auto rowp = fout + (size_t)m * w;
                                 lane_offset_here(out_off);
