@@ -19,8 +19,8 @@
 //           registers.
 // A WAVE owns a column of 16 output pixels and walks down a band of 16-row tiles with its input two tiles ahead in
 // registers; each H tile is computed once and used by two output blocks; the 32-pixel input window of a 16-pixel
-// column means every input pixel is loaded by two waves (HBM traffic stays 1.001 x algorithmic: the second read
-// hits a cache).  What the memory system needed (same-box ladder, 256 x 4K frames, k = 17):
+// column means every input pixel is loaded by two waves (HBM traffic stays 1.02 x algorithmic — the halo tile of
+// each band — the second read hits a cache).  What the memory system needed (same-box ladder, 256 x 4K frames, k = 17):
 //   * loads issued in the matrix arrangement (adjacent lanes = adjacent ROWS): every lane its own cache line, 3.35 TB/s
 //     -> issued coalesced (lane 4r + p reads piece p of row r) and moved to the matrix arrangement with
 //     ds_bpermute_b32: 3.94;
@@ -30,7 +30,8 @@
 //     5.0 (the LDS-staged kernel on that box: 4.3);
 //   * 68 blocks per band instead of 15: 5.2.
 //   Tried and dropped: hand-issued loads with a hand-placed s_waitcnt vmcnt(2) (hipcc drains the counter at the top
-//   of every step; counting by hand was 3 % SLOWER); 5 waves per SIMD (spills).
+//   of every step; counting by hand was 3 % SLOWER); one barrier per TWO blocks (32-row output tile: -3.5 %); 5 waves
+//   per SIMD (96 VGPRs: weights re-read from LDS, input one tile ahead instead of two: -13 %).
 #include <type_traits>
 
 #include "common.hpp"
