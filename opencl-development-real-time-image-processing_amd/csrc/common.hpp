@@ -32,6 +32,7 @@ inline const char* tune_env(const char* name)
 
 // 16-byte vector of four RGBA pixels (one dword each): the unit of every coalesced access
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ uint32_t luma_rgb(uint32_t r, uint32_t g, uint32_t b)

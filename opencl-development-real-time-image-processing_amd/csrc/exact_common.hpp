@@ -27,8 +27,9 @@ __device__ __forceinline__ float dppr(float v)  // lane l <- lane l+1
 // (u + 1 + t) % K, t = 0 .. K-1, and the rows are visited in IMAGE order, top to bottom — arrival order for a band
 // walking down, the reverse for a band walking up (UP).  u is a constant after unrolling, so every register index
 // is static.  Runs under a wave-uniform branch: EXEC is full, the DPP reads see every lane.
-template <int K, int J, bool UP>
-__device__ __forceinline__ float exact_sum(const float (&g)[K][4], int u, const float* __restrict__ w2)
+// PX = pixels per lane (4; 8 in pipe_slide8.hip).
+template <int K, int J, bool UP, int PX = 4>
+__device__ __forceinline__ float exact_sum(const float (&g)[K][PX], int u, const float* __restrict__ w2)
 {
     constexpr int R = K / 2;
     float sum = 0.0f;
@@ -38,7 +39,7 @@ __device__ __forceinline__ float exact_sum(const float (&g)[K][4], int u, const 
 #pragma unroll
         for (int kx = 0; kx < K; kx++) {
             const int col = J - R + kx;
-            const float val = (col < 0) ? dppl(r[4 + col]) : ((col > 3) ? dppr(r[col - 4]) : r[col]);
+            const float val = (col < 0) ? dppl(r[PX + col]) : ((col > PX - 1) ? dppr(r[col - PX]) : r[col]);
             sum = sum + val * w2[ky * K + kx];  // -ffp-contract=off: v_mul_f32 then v_add_f32
         }
     }

@@ -72,6 +72,10 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
 hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                            int nframes, const GaussCoef& coef, bool exact, int impl);
 bool pipe_slide_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
+// 8 pixels per lane (pipe_slide8.hip): k in {3,5}, width % 8 == 0, aligned buffers; the same bits
+bool pipe_slide8_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
+hipError_t launch_pipe_slide8(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                              const GaussCoef& coef);
 hipError_t launch_pipe_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                              const GaussCoef& coef);
 

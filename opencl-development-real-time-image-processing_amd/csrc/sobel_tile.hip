@@ -18,6 +18,7 @@
 //   pipeline(FAST) == sobel(gauss_FAST(gray(x))) bit for bit, and pipeline(EXACT) == the CPU chain.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "slide_common.hpp"
 
 namespace mi355 {
 
@@ -203,6 +204,19 @@ hipError_t launch_pipeline(hipStream_t stream, const uint8_t* d_in, uint8_t* d_o
 {
     // the sliding-window kernel is bit-exact with the CPU chain ("exact by exception", pipe_slide.hip), so it serves
     // both Gaussian modes; tables it cannot take (non-separable, asymmetric factor) arrive here with exact = true
+    {
+        // 8 pixels per lane (pipe_slide8.hip, the same bits) pays on big launches of wide rows at k = 5: same box,
+        // 4K frames, 4 / 8 pixels per lane (tools/pipe8_ab.sh): 256 frames 4.57 / 4.82 TB/s (another box 4.67 / 4.73),
+        // 128 frames 4.53 / 4.71, 64 frames 4.31 / 4.30, 8 frames 4.02 / 3.87, 1 frame 2.26 / 1.77; 640 x 512 x 4096
+        // 4.17 / 3.66 (80 octets = 2 strips of 40 lanes); k = 3: 4.84 / 4.91 on one box, 4.93 / 4.82 on another.
+        const int octs = w / 8, strips8 = (octs + kSlideLanesOutMax - 1) / kSlideLanesOutMax;
+        const int lanes8 = strips8 > 0 ? (octs + strips8 - 1) / strips8 : 0;
+        bool want8 = coef.k == 5 && lanes8 >= 56 && (size_t)w * h * nframes >= 1000000000ull;
+        if (const char* e = tune_env("MI355_PIPE8"))  // tuning build: 1 forces the 8-pixel kernel, 0 forbids it
+            want8 = atoi(e) != 0;
+        if (impl != 1 && want8 && pipe_slide8_supported(d_in, d_out, w, h, coef))
+            return launch_pipe_slide8(stream, d_in, d_out, w, h, nframes, coef);
+    }
     if (impl != 1 && pipe_slide_supported(d_in, d_out, w, h, coef))
         return launch_pipe_slide(stream, d_in, d_out, w, h, nframes, coef);
     const int k = coef.k, R = k / 2;

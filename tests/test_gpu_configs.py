@@ -419,3 +419,44 @@ def test_exact_mode_batches_and_full_frames(ctx, pkg, oracle):
         assert np.array_equal(ctx.gauss(noisy, 3, 0.8), oracle.gauss_rgba(noisy, 3, 0.8, threads=_threads(oracle)))
     finally:
         ctx.set_gauss_mode(pkg.GAUSS_FAST)
+
+
+# ---- the fused pipeline with 8 pixels per lane (csrc/pipe_slide8.hip) -----------------------------------------------
+_PIPE8_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import __graft_entry__ as entry
+from conftest import rand_rgba
+pkg = entry.load_package(); oracle = entry.load_oracle()
+bad = []
+with pkg.Context(0) as ctx:
+    for (n, h, w) in [(1, 2, 16), (2, 3, 24), (1, 40, 504), (2, 131, 1000), (1, 300, 1920), (1, 7, 3840), (3, 97, 496), (1, 64, 512)]:
+        for k, s in ((3, 0.8), (5, 1.5)):
+            for kind in ("noise", "synth", "flat"):
+                if kind == "noise":
+                    x = rand_rgba(h, w, seed=h + w + k, alpha=None, n=n)
+                elif kind == "synth":
+                    x = oracle.synth_rgba(w, h, n, first_frame=k, mode=1)
+                else:
+                    x = np.full((n, h, w, 4), 200, np.uint8); x[:, :, w // 2:, :3] = 31
+                got = ctx.pipeline(x, k, s)
+                for f in range(n):
+                    if not np.array_equal(got[f], oracle.pipeline_rgba(x[f], k, s)):
+                        bad.append((n, h, w, k, kind, f))
+print(bad)
+"""
+
+
+def test_pipeline_eight_pixels_per_lane():
+    """AUTO gives k = 5 launches of >= 10^9 pixels to pipe_slide8.hip (config 5's 512-frame launch above: same checksum
+    as the 4-pixel kernel's 8 x 64 frames, frames equal to the oracle).  Here the tuning build forces it
+    (MI355_PIPE8=1) on small shapes: one strip / several strips / idle lanes, one band / several bands walking both
+    ways, image edges, k = 3 and 5, noise, smooth and flat frames — bit-identical to the chained oracle."""
+    root = entry.ROOT
+    tune_lib = os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so")
+    assert os.path.exists(tune_lib), "run __graft_entry__.build()"
+    env = dict(os.environ, MI355_IMGFILTER_LIB=tune_lib, MI355_PIPE8="1")
+    out = subprocess.run([sys.executable, "-c", _PIPE8_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "[]", out.stdout[-2000:]
