@@ -69,8 +69,9 @@ int mi355_ctx_set_gauss_mode(mi355_ctx* ctx, int mode);
  *          k in {3,5} (any width); the matrix-core kernel for odd 7 <= k <= 17 when width % 4 == 0, width >= 64,
  *          the launch has >= 2^16 pixels and the device buffers are 16-byte aligned, the VALU kernels otherwise
  *          (k in {7,9} any width; k in {11,13,15,17} with an even width); the LDS-tiled kernel for everything else.
- *          EXACT mode: the exact-by-exception sliding kernel for k in {3,5} and width % 4 == 0, the tiled kernel
- *          otherwise.  Pipeline: k in {3,5,7}, w >= 4, h >= 2 sliding, tiled otherwise.
+ *          EXACT mode: the exact-by-exception sliding kernel for k in {3,5,7} and width % 4 == 0, the tiled kernel
+ *          otherwise.  Pipeline: k in {3,5,7}, w >= 4, h >= 2 sliding (8 pixels per lane for k = 5 launches of
+ *          >= 10^9 pixels with width % 8 == 0), tiled otherwise.
  *   TILE — always the LDS-tiled kernels.
  *   VALU — as AUTO but never the matrix cores.  TILE and VALU give identical bits. */
 #define MI355_IMPL_AUTO 0

@@ -1,7 +1,8 @@
 // gauss_exact.hip — the EXACT-mode Gaussian (bit-identical to the reference CPU path,
-// src/GaussianBlur/GaussianBlur.cpp:234-261) at sliding-window speed, k in {3, 5}.  gfx950 only.
-// (k = 7: four channels x 49-tap chains x two walking directions per row is more code than hipcc unrolls — the ring
-// ends up in scratch memory — so k >= 7 stays with the tiled EXACT kernel.)
+// src/GaussianBlur/GaussianBlur.cpp:234-261) at sliding-window speed, k in {3, 5, 7}.  gfx950 only.
+// (k = 7: four channels x 49-tap chains x two walking directions per row is more code than LLVM's default budget for
+// `#pragma unroll` — the loop stayed rolled and the ring went to scratch memory; the Makefile raises the budget for
+// this file.)
 //
 // MI355_GAUSS_EXACT used to mean the LDS-tiled kernel evaluating the CPU path's own k*k-term chain for every value
 // (2 k^2 operations per channel: 1.0 TB/s at k = 5 on 64 x 4K frames; this kernel: 4.7 TB/s, same box).  This kernel is "exact by exception" (exact_common.hpp, the
@@ -207,8 +208,8 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     constexpr int K = 2 * R + 1;
     const StripPlan sp = make_strip_plan(w);
     BandPlan plan;
-    constexpr int kRows = (R == 1) ? 16 : 24;
-    constexpr int kWavesPerSimd = (R == 1) ? 5 : 3;
+    constexpr int kRows = (R == 1) ? 16 : (R == 2 ? 24 : 40);
+    constexpr int kWavesPerSimd = (R == 1) ? 5 : (R == 2 ? 3 : 2);
     if (!make_band_plan(h, sp.nstrips, nframes, kWavesPerSimd, kRows, kRows, kRows, 0.0, kRows / 2, &plan))
         return hipErrorInvalidValue;
     ETables<K> tab;
@@ -240,20 +241,21 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
 
 }  // namespace
 
-// k in {3, 5}, width a multiple of 4, 16-byte aligned buffers, a separable table with a symmetric factor and a
+// k in {3, 5, 7}, width a multiple of 4, 16-byte aligned buffers, a separable table with a symmetric factor and a
 // useful error bound (everything mi355_gauss_weights generates qualifies)
 bool gauss_exact_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef)
 {
     (void)h;
     const int k = coef.k;
-    if ((k != 3 && k != 5) || !coef.separable || !coef.h_w2d)
+    if ((k != 3 && k != 5 && k != 7) || !coef.separable || !coef.h_w2d)
         return false;
     if ((w & 3) != 0 || ((reinterpret_cast<uintptr_t>(d_in) | reinterpret_cast<uintptr_t>(d_out)) & 15u) != 0)
         return false;
     for (int j = 0; j < k / 2; j++)
         if (coef.h_w1d[j] != coef.h_w1d[k - 1 - j])
             return false;
-    const double delta = (k == 3) ? delta_bound<3>(coef.h_w1d, coef.h_w2d) : delta_bound<5>(coef.h_w1d, coef.h_w2d);
+    const double delta = (k == 3) ? delta_bound<3>(coef.h_w1d, coef.h_w2d)
+                                  : (k == 5 ? delta_bound<5>(coef.h_w1d, coef.h_w2d) : delta_bound<7>(coef.h_w1d, coef.h_w2d));
     return delta < 0.01;
 }
 
@@ -263,6 +265,7 @@ hipError_t launch_gauss_exact(hipStream_t stream, const uint8_t* d_in, uint8_t* 
     switch (coef.k) {
     case 3: return launch_r<1>(stream, d_in, d_out, w, h, nframes, coef);
     case 5: return launch_r<2>(stream, d_in, d_out, w, h, nframes, coef);
+    case 7: return launch_r<3>(stream, d_in, d_out, w, h, nframes, coef);
     default: return hipErrorInvalidValue;
     }
 }

@@ -49,7 +49,7 @@ size_t gauss_wide_flag_items(int w, int h, int nframes, int k);
 hipError_t launch_gauss_wide(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                              const GaussCoef& coef, uint32_t* d_flags);
 
-// EXACT-mode sliding-window kernel (gauss_exact.hip): k in {3,5}, width % 4 == 0, 16-byte aligned buffers;
+// EXACT-mode sliding-window kernel (gauss_exact.hip): k in {3,5,7}, width % 4 == 0, 16-byte aligned buffers;
 // bit-identical to the CPU path ("exact by exception")
 bool gauss_exact_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
 hipError_t launch_gauss_exact(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,

@@ -377,7 +377,7 @@ def test_image2d_mode_fixture(ctx, pkg, oracle, fixture_rgba):
 
 
 # ---- EXACT mode at sliding-window speed (csrc/gauss_exact.hip) -----------------------------------------------------
-@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5)])
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0)])
 @pytest.mark.parametrize("h,w", [(1, 4), (2, 8), (7, 12), (40, 252), (33, 248), (131, 500), (300, 1920), (5, 3840)])
 def test_exact_mode_sliding_kernel(ctx, pkg, oracle, k, sigma, h, w):
     """MI355_GAUSS_EXACT on 4-pixel-multiple widths runs the exact-by-exception sliding kernel: bit-identical to the CPU
