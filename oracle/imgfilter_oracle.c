@@ -11,14 +11,26 @@
  *     Controller::_GenerateGausianKernel compiled from /root/reference
  *     (oracle/_ref, tests/test_oracle.py::test_weights_against_live_reference_build) and by committed vectors that
  *     build produced (tests/golden/gauss_weights_ref.json).
- *   - oracle_gray_*, oracle_gauss_rgba, oracle_sobel_* : PARITY UNPINNED.  The
- *     reference keeps those loops inside translation units that include
- *     <opencv2/opencv.hpp> (absent here, not installable) and ships no tests,
- *     golden outputs or fixtures for them.  They are restated line by line from
- *     the cited source and pinned only by hand-derivable known answers.
- *   - Sobel additionally restates OpenCV's *documented* filter2D / magnitude /
- *     convertTo semantics (OpenCV is an un-vendored, un-pinned apt dependency of
- *     the reference: libopencv-dev, .github/workflows/ci.yml:33).
+ *   - oracle_gray_*, oracle_gauss_rgba, oracle_sobel_gray : PINNED BY THE REFERENCE'S
+ *     PUBLISHED OUTPUTS (round 2).  The reference keeps those loops inside
+ *     translation units that include <opencv2/opencv.hpp> (absent here, not
+ *     installable) and ships no golden images — but its benchmark applications
+ *     published, per test image, Error_MAE = mean |CPU path - OpenCL path|
+ *     (src/{Grayscale,GaussianBlur,EdgeDetection}/results/Linux_100_*_sorted_results.csv,
+ *     24 numbers, 6 significant digits).  tests/test_published_mae.py recomputes
+ *     them from this file (the CPU operand) and oracle/opencl_path.py (the OpenCL
+ *     kernels' arithmetic) on the reference's own images: grayscale 8 of 8 and
+ *     Gaussian 8 of 8 to the last printed digit; Sobel 4 of 8 to the last digit
+ *     and 8 of 8 inside the bracket the OpenCL device's sqrt rounding leaves open.
+ *     Misreadings of the CPU path (integer or float luminance, fused multiply-adds,
+ *     other border rules, truncation) miss those numbers (negative controls there).
+ *   - Sobel restates OpenCV's documented filter2D / magnitude / convertTo
+ *     semantics (OpenCV is an un-vendored, un-pinned apt dependency of the
+ *     reference: libopencv-dev, .github/workflows/ci.yml:33); the published
+ *     EdgeDetection numbers are what ties that restatement to the OpenCV build the
+ *     reference's author ran.
+ *   - oracle_pipeline_rgba (build-defined chain) and oracle_image2d_* (no CPU twin
+ *     and no published number in the reference): parity unpinned.
  *
  * Build: plain C, -O2 -ffp-contract=off, no -march flags (the reference is a
  * default x86-64 build: no FMA contraction can occur there).

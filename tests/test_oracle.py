@@ -67,7 +67,8 @@ def test_weights_known_values(oracle):
         oracle.gauss_weights(4, 1.0)
 
 
-# ---- grayscale: parity unpinned; known answers + independent restatement ---------------------
+# ---- grayscale: known answers + independent restatement (pinned by the reference's published numbers in
+#      test_published_mae.py) -----------------------------------------------------------------
 def test_gray_known_answers(oracle):
     assert oracle.gray_px(0, 72, 24) == 44      # exact rational value is 45.0; the double sum is below
     assert oracle.gray_px(255, 255, 255) == 255
@@ -102,7 +103,7 @@ def test_gray_config1_fixture(oracle, fixture_rgb, regression):
     assert np.array_equal(oracle.gray_rgba_1ch(rgba), out)   # layout does not change the value
 
 
-# ---- Gaussian: parity unpinned; known answers -------------------------------------------------
+# ---- Gaussian: known answers (pinned by the reference's published numbers in test_published_mae.py) ---
 def test_gauss_constant_images(oracle):
     for v, expect in ((255, 254), (128, 128), (200, 200), (0, 0)):
         out = oracle.gauss_rgba(np.full((9, 11, 4), v, np.uint8), 5, 1.5)
@@ -161,7 +162,7 @@ def test_gauss_tiny_and_ragged_sizes(oracle):
     assert np.array_equal(oracle.gauss_rgba(img, 5, 1.5), oracle.gauss_rgba(img, 5, 1.5, threads=4))
 
 
-# ---- Sobel: parity unpinned (restated OpenCV semantics) --------------------------------------
+# ---- Sobel: restated OpenCV semantics; known answers (published numbers: test_published_mae.py) -------
 def test_sobel_known_answers(oracle):
     assert oracle.sobel_gray(np.full((5, 7), 77, np.uint8)).max() == 0         # flat -> 0, border too
     step = np.zeros((8, 10), np.uint8)

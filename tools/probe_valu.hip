@@ -45,6 +45,29 @@ PROBE(k_fma_mix_lo, "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]\n v_fma_mix_
 PROBE(k_fma_mix_hi, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %2, %3, %4, %2 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %3, %4, %5, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %4, %5, %6, %4 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %5, %6, %7, %5 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %6, %7, %0, %6 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n v_fma_mix_f32 %7, %0, %1, %7 op_sel:[0,1,0] op_sel_hi:[0,1,0]\n")
 PROBE(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %1, %2\n v_cvt_pkrtz_f16_f32 %1, %2, %3\n v_cvt_pkrtz_f16_f32 %2, %3, %4\n v_cvt_pkrtz_f16_f32 %3, %4, %5\n v_cvt_pkrtz_f16_f32 %4, %5, %6\n v_cvt_pkrtz_f16_f32 %5, %6, %7\n v_cvt_pkrtz_f16_f32 %6, %7, %0\n v_cvt_pkrtz_f16_f32 %7, %0, %1\n")
 
+PROBE(k_pk_fma_f16, "v_pk_fma_f16 %0, %1, %2, %0\n v_pk_fma_f16 %1, %2, %3, %1\n v_pk_fma_f16 %2, %3, %4, %2\n v_pk_fma_f16 %3, %4, %5, %3\n v_pk_fma_f16 %4, %5, %6, %4\n v_pk_fma_f16 %5, %6, %7, %5\n v_pk_fma_f16 %6, %7, %0, %6\n v_pk_fma_f16 %7, %0, %1, %7\n")
+PROBE(k_pk_add_f16, "v_pk_add_f16 %0, %1, %2\n v_pk_add_f16 %1, %2, %3\n v_pk_add_f16 %2, %3, %4\n v_pk_add_f16 %3, %4, %5\n v_pk_add_f16 %4, %5, %6\n v_pk_add_f16 %5, %6, %7\n v_pk_add_f16 %6, %7, %0\n v_pk_add_f16 %7, %0, %1\n")
+PROBE(k_pk_mul_f16, "v_pk_mul_f16 %0, %1, %2\n v_pk_mul_f16 %1, %2, %3\n v_pk_mul_f16 %2, %3, %4\n v_pk_mul_f16 %3, %4, %5\n v_pk_mul_f16 %4, %5, %6\n v_pk_mul_f16 %5, %6, %7\n v_pk_mul_f16 %6, %7, %0\n v_pk_mul_f16 %7, %0, %1\n")
+PROBE(k_dot2_f32_f16, "v_dot2_f32_f16 %0, %1, %2, %0\n v_dot2_f32_f16 %1, %2, %3, %1\n v_dot2_f32_f16 %2, %3, %4, %2\n v_dot2_f32_f16 %3, %4, %5, %3\n v_dot2_f32_f16 %4, %5, %6, %4\n v_dot2_f32_f16 %5, %6, %7, %5\n v_dot2_f32_f16 %6, %7, %0, %6\n v_dot2_f32_f16 %7, %0, %1, %7\n")
+PROBE(k_dot2c_f32_f16, "v_dot2c_f32_f16 %0, %1, %2\n v_dot2c_f32_f16 %1, %2, %3\n v_dot2c_f32_f16 %2, %3, %4\n v_dot2c_f32_f16 %3, %4, %5\n v_dot2c_f32_f16 %4, %5, %6\n v_dot2c_f32_f16 %5, %6, %7\n v_dot2c_f32_f16 %6, %7, %0\n v_dot2c_f32_f16 %7, %0, %1\n")
+PROBE(k_sqrt_f32, "v_sqrt_f32 %0, %1\n v_sqrt_f32 %1, %2\n v_sqrt_f32 %2, %3\n v_sqrt_f32 %3, %4\n v_sqrt_f32 %4, %5\n v_sqrt_f32 %5, %6\n v_sqrt_f32 %6, %7\n v_sqrt_f32 %7, %0\n")
+PROBE(k_mul_hi_u24, "v_mul_hi_u32_u24 %0, %1, %2\n v_mul_hi_u32_u24 %1, %2, %3\n v_mul_hi_u32_u24 %2, %3, %4\n v_mul_hi_u32_u24 %3, %4, %5\n v_mul_hi_u32_u24 %4, %5, %6\n v_mul_hi_u32_u24 %5, %6, %7\n v_mul_hi_u32_u24 %6, %7, %0\n v_mul_hi_u32_u24 %7, %0, %1\n")
+PROBE(k_mul_u24, "v_mul_u32_u24 %0, %1, %2\n v_mul_u32_u24 %1, %2, %3\n v_mul_u32_u24 %2, %3, %4\n v_mul_u32_u24 %3, %4, %5\n v_mul_u32_u24 %4, %5, %6\n v_mul_u32_u24 %5, %6, %7\n v_mul_u32_u24 %6, %7, %0\n v_mul_u32_u24 %7, %0, %1\n")
+PROBE(k_dot4_u8, "v_dot4_u32_u8 %0, %1, %2, %0\n v_dot4_u32_u8 %1, %2, %3, %1\n v_dot4_u32_u8 %2, %3, %4, %2\n v_dot4_u32_u8 %3, %4, %5, %3\n v_dot4_u32_u8 %4, %5, %6, %4\n v_dot4_u32_u8 %5, %6, %7, %5\n v_dot4_u32_u8 %6, %7, %0, %6\n v_dot4_u32_u8 %7, %0, %1, %7\n")
+PROBE(k_cvt_f32_u32, "v_cvt_f32_u32 %0, %1\n v_cvt_f32_u32 %1, %2\n v_cvt_f32_u32 %2, %3\n v_cvt_f32_u32 %3, %4\n v_cvt_f32_u32 %4, %5\n v_cvt_f32_u32 %5, %6\n v_cvt_f32_u32 %6, %7\n v_cvt_f32_u32 %7, %0\n")
+PROBE(k_min_f32, "v_min_f32 %0, %1, %2\n v_min_f32 %1, %2, %3\n v_min_f32 %2, %3, %4\n v_min_f32 %3, %4, %5\n v_min_f32 %4, %5, %6\n v_min_f32 %5, %6, %7\n v_min_f32 %6, %7, %0\n v_min_f32 %7, %0, %1\n")
+PROBE(k_fract_f32, "v_fract_f32 %0, %1\n v_fract_f32 %1, %2\n v_fract_f32 %2, %3\n v_fract_f32 %3, %4\n v_fract_f32 %4, %5\n v_fract_f32 %5, %6\n v_fract_f32 %6, %7\n v_fract_f32 %7, %0\n")
+PROBE(k_lshlrev, "v_lshlrev_b32 %0, 2, %1\n v_lshlrev_b32 %1, 2, %2\n v_lshlrev_b32 %2, 2, %3\n v_lshlrev_b32 %3, 2, %4\n v_lshlrev_b32 %4, 2, %5\n v_lshlrev_b32 %5, 2, %6\n v_lshlrev_b32 %6, 2, %7\n v_lshlrev_b32 %7, 2, %0\n")
+PROBE(k_lshl_add, "v_lshl_add_u32 %0, %1, 8, %2\n v_lshl_add_u32 %1, %2, 8, %3\n v_lshl_add_u32 %2, %3, 8, %4\n v_lshl_add_u32 %3, %4, 8, %5\n v_lshl_add_u32 %4, %5, 8, %6\n v_lshl_add_u32 %5, %6, 8, %7\n v_lshl_add_u32 %6, %7, 8, %0\n v_lshl_add_u32 %7, %0, 8, %1\n")
+PROBE(k_add_f32, "v_add_f32 %0, %1, %2\n v_add_f32 %1, %2, %3\n v_add_f32 %2, %3, %4\n v_add_f32 %3, %4, %5\n v_add_f32 %4, %5, %6\n v_add_f32 %5, %6, %7\n v_add_f32 %6, %7, %0\n v_add_f32 %7, %0, %1\n")
+PROBE(k_cvt_f16_f32, "v_cvt_f16_f32 %0, %1\n v_cvt_f16_f32 %1, %2\n v_cvt_f16_f32 %2, %3\n v_cvt_f16_f32 %3, %4\n v_cvt_f16_f32 %4, %5\n v_cvt_f16_f32 %5, %6\n v_cvt_f16_f32 %6, %7\n v_cvt_f16_f32 %7, %0\n")
+PROBE(k_pack_b32_f16, "v_pack_b32_f16 %0, %1, %2\n v_pack_b32_f16 %1, %2, %3\n v_pack_b32_f16 %2, %3, %4\n v_pack_b32_f16 %3, %4, %5\n v_pack_b32_f16 %4, %5, %6\n v_pack_b32_f16 %5, %6, %7\n v_pack_b32_f16 %6, %7, %0\n v_pack_b32_f16 %7, %0, %1\n")
+PROBE(k_mad_u32_u24, "v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %1, %2, %3, %1\n v_mad_u32_u24 %2, %3, %4, %2\n v_mad_u32_u24 %3, %4, %5, %3\n v_mad_u32_u24 %4, %5, %6, %4\n v_mad_u32_u24 %5, %6, %7, %5\n v_mad_u32_u24 %6, %7, %0, %6\n v_mad_u32_u24 %7, %0, %1, %7\n")
+PROBE(k_pk_add_u16, "v_pk_add_u16 %0, %1, %2\n v_pk_add_u16 %1, %2, %3\n v_pk_add_u16 %2, %3, %4\n v_pk_add_u16 %3, %4, %5\n v_pk_add_u16 %4, %5, %6\n v_pk_add_u16 %5, %6, %7\n v_pk_add_u16 %6, %7, %0\n v_pk_add_u16 %7, %0, %1\n")
+PROBE(k_pk_mad_u16, "v_pk_mad_u16 %0, %1, %2, %0\n v_pk_mad_u16 %1, %2, %3, %1\n v_pk_mad_u16 %2, %3, %4, %2\n v_pk_mad_u16 %3, %4, %5, %3\n v_pk_mad_u16 %4, %5, %6, %4\n v_pk_mad_u16 %5, %6, %7, %5\n v_pk_mad_u16 %6, %7, %0, %6\n v_pk_mad_u16 %7, %0, %1, %7\n")
+PROBE(k_sqrt_f16, "v_sqrt_f16 %0, %1\n v_sqrt_f16 %1, %2\n v_sqrt_f16 %2, %3\n v_sqrt_f16 %3, %4\n v_sqrt_f16 %4, %5\n v_sqrt_f16 %5, %6\n v_sqrt_f16 %6, %7\n v_sqrt_f16 %7, %0\n")
+PROBE(k_rsq_f32, "v_rsq_f32 %0, %1\n v_rsq_f32 %1, %2\n v_rsq_f32 %2, %3\n v_rsq_f32 %3, %4\n v_rsq_f32 %4, %5\n v_rsq_f32 %5, %6\n v_rsq_f32 %6, %7\n v_rsq_f32 %7, %0\n")
+
 template <typename K> void run(const char* name, K kern, uint64_t* d)
 {
     for (int waves_per_simd : {1, 2, 4}) {
@@ -102,6 +125,28 @@ int main()
     run("v_fma_mix_f32 lo", k_fma_mix_lo, d);
     run("v_fma_mix_f32 hi", k_fma_mix_hi, d);
     run("v_cvt_pkrtz_f16", k_cvt_pkrtz, d);
+    run("v_pk_fma_f16", k_pk_fma_f16, d);
+    run("v_pk_add_f16", k_pk_add_f16, d);
+    run("v_pk_mul_f16", k_pk_mul_f16, d);
+    run("v_dot2_f32_f16", k_dot2_f32_f16, d);
+    run("v_dot2c_f32_f16", k_dot2c_f32_f16, d);
+    run("v_sqrt_f32", k_sqrt_f32, d);
+    run("v_mul_hi_u32_u24", k_mul_hi_u24, d);
+    run("v_mul_u32_u24", k_mul_u24, d);
+    run("v_dot4_u32_u8", k_dot4_u8, d);
+    run("v_cvt_f32_u32", k_cvt_f32_u32, d);
+    run("v_min_f32", k_min_f32, d);
+    run("v_fract_f32", k_fract_f32, d);
+    run("v_lshlrev_b32", k_lshlrev, d);
+    run("v_lshl_add_u32", k_lshl_add, d);
+    run("v_add_f32", k_add_f32, d);
+    run("v_cvt_f16_f32", k_cvt_f16_f32, d);
+    run("v_pack_b32_f16", k_pack_b32_f16, d);
+    run("v_mad_u32_u24", k_mad_u32_u24, d);
+    run("v_pk_add_u16", k_pk_add_u16, d);
+    run("v_pk_mad_u16", k_pk_mad_u16, d);
+    run("v_sqrt_f16", k_sqrt_f16, d);
+    run("v_rsq_f32", k_rsq_f32, d);
     for (int mode : {0, 1}) for (int w : {1, 2, 4}) {
         hipMemset(d, 0, 16 * 8 * 256);
         hipLaunchKernelGGL(k_pk, dim3(256), dim3(256 * w), 0, 0, d, 1.0f, mode); hipDeviceSynchronize();
