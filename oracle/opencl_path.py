@@ -124,3 +124,29 @@ def cl_sobel(rgba, contraction="published", division="rcp", sqrt_ulps=0, border=
     m = np.clip(m, f32(0.0), f32(1.0))
     out[1:-1, 1:-1] = (m * f32(255.0)).astype(np.uint8)
     return out
+
+
+def cl_sobel_image2d(rgba, sqrt_ulps=0):
+    """src/EdgeDetection/kernel/edge_images.cl:9-46 (= RT/kernel/edge_images.cl): red channel of the normalised texel
+    (byte / 255.0f), interior pixels only, sqrt, clamp to [0, 1]; read back as float and converted by uchar(f * 255.0f).
+    No luminance expression, hence no contraction freedom: only the device's sqrt is open.  With sqrt_ulps = 0 this is
+    oracle_image2d_sobel (imgfilter_oracle.c) bit for bit."""
+    h, w, _ = rgba.shape
+    out = np.zeros((h, w), np.uint8)
+    if h < 3 or w < 3:
+        return out
+    px = rgba[..., 0].astype(f32) / f32(255.0)
+    gx = np.zeros((h - 2, w - 2), f32)
+    gy = np.zeros((h - 2, w - 2), f32)
+    for ky in range(3):
+        for kx in range(3):
+            t = px[ky:ky + h - 2, kx:kx + w - 2]
+            gx = (gx + t * f32(_SX[ky][kx])).astype(f32)
+            gy = (gy + t * f32(_SY[ky][kx])).astype(f32)
+    arg = (gx * gx + gy * gy).astype(f32)
+    m = np.sqrt(arg)
+    if sqrt_ulps:
+        m = np.where(arg > 0, (np.ascontiguousarray(m).view(np.int32) + sqrt_ulps).view(f32), m)
+    m = np.clip(m, f32(0.0), f32(1.0))
+    out[1:-1, 1:-1] = (m * f32(255.0)).astype(np.uint8)
+    return out

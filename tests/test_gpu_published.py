@@ -87,3 +87,18 @@ def test_hip_sobel_on_the_decoder_luma_plane(ctx, oracle, ref_images):
                 ok &= same[dy:dy + h, dx:dx + w]
         assert np.array_equal(hip[ok], oracle.sobel_gray(np.ascontiguousarray(y))[ok]), n
         assert ok.mean() > 0.05, (n, ok.mean())
+
+
+def test_hip_image2d_mode_reproduces_the_published_windows_numbers(ctx, pkg, oracle, ref_images):
+    """The reference's Windows runs went through its image2d_t kernels (test_published_mae.py).  The product's
+    image2d-mode entry (mi355_image2d_rgba8) in the OpenCL path's seat, the HIP buffer-mode grayscale /
+    the oracle's CPU Sobel in the CPU path's: grayscale to the last printed digit, Sobel within 2e-5."""
+    for n, (rgb, y) in ref_images.items():
+        rgba = rgba_of(rgb)
+        img_gray, _ = ctx.image2d(pkg.FILTER_GRAY, rgba)
+        assert np.array_equal(img_gray, oracle.image2d_gray(rgba).reshape(img_gray.shape)), n
+        assert printed(mae(ctx.gray1(rgba), img_gray)) == published("gray", n, "Windows"), n
+        img_sobel, _ = ctx.image2d(pkg.FILTER_SOBEL, rgba)
+        assert np.array_equal(img_sobel, oracle.image2d_sobel(rgba).reshape(img_sobel.shape)), n
+        pub = published("sobel", n, "Windows")
+        assert abs(mae(oracle.sobel_gray(np.ascontiguousarray(y)), img_sobel) - pub) / pub < 2e-5, n

@@ -12,11 +12,12 @@ the two largest where /root/reference exists):
               where the reference's double-precision formula truncates one below the integer formula, so those four
               numbers pin exactly the 3,464-colour exception set the product's fast luminance has to honour
   Gaussian    8 of 8 (0, 0, 0, 2, 1, 2, 11, 42 differing blue-channel bytes)
-  Sobel       4 of 8 to the last digit, the other four inside the bracket spanned by a correctly rounded and a
-              1-ulp-high device sqrt (the OpenCL side's magnitude * 255 lands on exact integers wherever the gradient
-              has one direction only, so the unknown device's sqrt rounding decides those pixels; the CPU side — what
-              the oracle restates: decoder luma, filter2D as correlation with BORDER_REFLECT_101, magnitude,
-              round-to-nearest + saturate — has no such freedom)
+  Sobel       Linux run (buffer kernel): 4 of 8 to the last digit, the other four inside the bracket spanned by a
+              correctly rounded and a 1-ulp-high device sqrt (the OpenCL side's magnitude * 255 lands on exact integers
+              wherever the gradient has one direction only, so the unknown device's sqrt rounding decides those pixels;
+              the CPU side — what the oracle restates: decoder luma, filter2D as correlation with BORDER_REFLECT_101,
+              magnitude, round-to-nearest + saturate — has no such freedom).  Windows run (image2d kernel, no luminance
+              arithmetic on the OpenCL side): 5 of 8 to the last digit, all 8 within 2e-5 relative
 and the negative controls show that the comparison discriminates: plausible misreadings of the CPU path (integer
 luminance, REPLICATE / REFLECT borders, truncation, luma recomputed from RGB) miss the published numbers.
 """
@@ -133,6 +134,25 @@ def test_gray_device_identification_is_unique(oracle, images):
     assert hits == [("published", "rcp")]
 
 
+def test_gray_windows_numbers_are_the_image2d_path(oracle, images):
+    """The reference's WINDOWS grayscale run went through grayscale_images.cl (normalised texels, R/FLOAT output,
+    ConvertToUChar): CPU path against oracle_image2d_gray reproduces all 8 numbers of
+    src/Grayscale/results/Windows_100_*_sorted_results.csv to the last digit (2, 11, 159, 363, 401, 3162, 21818, 36127
+    differing pixels) — with the same contraction of the luminance expression as the Linux device chose, and with none
+    other (the uncontracted form gives 1, 14, 172, 392, ...).  A second set of eight published numbers behind
+    oracle_gray_*, and the pin of oracle_image2d_gray / the product's image2d grayscale."""
+    for n, (rgb, _) in images.items():
+        cpu = oracle.gray_bgr(np.ascontiguousarray(rgb[..., ::-1]))
+        img = oracle.image2d_gray(rgba_of(rgb)).reshape(cpu.shape)
+        assert printed(mae(cpu, img)) == published("gray", n, "Windows"), (n, (cpu != img).sum())
+    # the uncontracted form is rejected
+    rgb = images["Tulips_medium640"][0]
+    x, y, z = (rgb[..., i].astype(np.float32) / np.float32(255.0) for i in range(3))
+    plain = ((np.float32(0.299) * x + np.float32(0.587) * y) + np.float32(0.114) * z) * np.float32(255.0)
+    cpu = oracle.gray_bgr(np.ascontiguousarray(rgb[..., ::-1]))
+    assert printed(mae(cpu, plain.astype(np.uint8))) != published("gray", "Tulips_medium640", "Windows")
+
+
 def test_gray_negative_controls(oracle, images):
     """Misreadings of the CPU path (grayscale.cpp:237) that the published numbers reject."""
     miss_int = miss_f32 = 0
@@ -214,6 +234,27 @@ def test_sobel_published_numbers(oracle, images):
         assert printed(lo) - 1e-9 <= pub <= printed(hi) + 1e-9, (n, lo, pub, hi)
         assert (hi - lo) / pub < 0.02  # the bracket is narrow: < 2 % of the number it brackets
     assert exact >= (4 if len(images) == 8 else 4)
+
+
+def test_sobel_windows_numbers_are_the_image2d_path(oracle, images):
+    """The reference's WINDOWS EdgeDetection run (src/EdgeDetection/results/Windows_100_*_sorted_results.csv, MAE 8-48)
+    went through the image2d_t kernel (edge_images.cl: red channel, no luminance): the CPU Sobel against the image-mode
+    restatement reproduces 5 of its 8 numbers to the last digit and all 8 inside the bracket of a correctly rounded / a
+    1-ulp-low device sqrt.  A second, independent tie of oracle_sobel_gray to the OpenCV build the author ran — with no
+    luminance arithmetic on the OpenCL side at all — and the pin of oracle_image2d_sobel."""
+    exact = 0
+    for n, (rgb, y) in images.items():
+        rgba = rgba_of(rgb)
+        cpu = oracle.sobel_gray(np.ascontiguousarray(y))
+        img0 = CL.cl_sobel_image2d(rgba)
+        assert np.array_equal(img0, oracle.image2d_sobel(rgba).reshape(img0.shape)), n
+        a, b = mae(cpu, img0), mae(cpu, CL.cl_sobel_image2d(rgba, sqrt_ulps=-1))
+        pub = published("sobel", n, "Windows")
+        exact += printed(a) == pub
+        lo, hi = sorted((printed(a), printed(b)))
+        assert lo - 1e-9 <= pub <= hi + 1e-9, (n, a, pub, b)
+        assert abs(a - pub) / pub < 2e-5, n  # the correctly rounded form alone is within 2e-5 of every number
+    assert exact >= (5 if len(images) == 8 else 3)
 
 
 def test_sobel_negative_controls(oracle, images):
