@@ -73,18 +73,40 @@ double delta_bound(const float* w1, const float* w2)
     for (int i = 0; i < K; i++)
         for (int j = 0; j < K; j++)
             mismatch += std::fabs((double)w1[i] * (double)w1[j] - (double)w2[i * K + j]);
-    // CPU path: k*k products (each rounded), k*k additions (each rounded; partial sums <= 255 * sum2)
-    const double e_cpu = K * K * half_ulp(255.0 * max2) + K * K * half_ulp(255.0 * sum2);
-    // kernel, vertical: R + 1 multiply-adds on values <= 255 * sum1 (the integer pair sums are exact)
+    // CPU path (GaussianBlur.cpp:243-256): term i (row-major, ky outer / kx inner) is a product of a byte and w2[i],
+    // rounded (error <= half an ulp of 255 * w2[i]), added to the running sum, rounded again — and the running sum
+    // after term i cannot exceed 255 * (w2[0] + ... + w2[i]) plus the error made so far (every term is non-negative),
+    // so the early additions happen in low binades.  (Round 2, second half: the bound used to charge every product
+    // with the largest weight's ulp and every addition with the final sum's: 2.1e-4 at k = 5, now 1.4e-4.)
+    double e_cpu = 0.0, cum = 0.0;
+    for (int i = 0; i < K * K; i++) {
+        cum += (double)w2[i];
+        e_cpu += half_ulp(255.0 * (double)w2[i]) + half_ulp(255.0 * cum + 1e-3);
+    }
+    (void)max2;
+    // kernel, vertical: acc = w(0) g_c, then acc = fma(w(d), g_{c-d} + g_{c+d}, acc), d = 1 .. R (the integer pair sums
+    // are exact): R + 1 roundings, the one after distance d of a value <= 255 * c_d, c_d = w(0) + 2 (w(1) + ... + w(d))
     const double tv = 255.0 * sum1;
-    const double e_v = (R + 1) * half_ulp(tv);
-    // kernel, horizontal: R pair sums of vertical results (<= 2 tv each, weighted), R + 1 multiply-adds on values
-    // <= 255 * sum1^2, plus the vertical error carried through weights that sum to sum1
+    double c_d = (double)w1[R];
+    double e_v = half_ulp(255.0 * c_d);
+    for (int d = 1; d <= R; d++) {
+        c_d += 2.0 * (double)w1[R - d];
+        e_v += half_ulp(255.0 * c_d + 1e-3);
+    }
+    // kernel, horizontal: acc = fma(w(0), v_c, delta), then acc = fma(w(d), v_{c-d} + v_{c+d}, acc): the R pair sums are
+    // rounded float additions of values <= tv (weighted by w(d) afterwards), the R + 1 fused operations round values
+    // <= tv * c_d + delta (delta < 0.01, checked by the callers); the vertical error arrives through weights summing to sum1
     double e_pairs = 0.0;
     for (int d = 1; d <= R; d++)
-        e_pairs += (double)w1[R - d] * half_ulp(2.0 * tv);
-    // (+1: the centre tap carries + delta, one more rounding of a value of that size)
-    const double e_h = e_v * sum1 + e_pairs + (R + 2) * half_ulp(255.0 * sum1 * sum1 + 0.01);
+        e_pairs += (double)w1[R - d] * half_ulp(2.0 * tv + 1e-3);
+    c_d = (double)w1[R];
+    double e_chain = half_ulp(tv * c_d + 0.011);
+    for (int d = 1; d <= R; d++) {
+        c_d += 2.0 * (double)w1[R - d];
+        e_chain += half_ulp(tv * c_d + 0.011);
+    }
+    const double e_h = e_v * sum1 + e_pairs + e_chain;
+    (void)sum2;
     // every term above is a worst case already; the margin only covers the double arithmetic of this function
     return 1.02 * (e_cpu + e_h + 255.0 * mismatch) + 1e-7;
 }
