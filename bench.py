@@ -82,6 +82,9 @@ def parse(argv=None):
     p.add_argument("--no-side-figures", action="store_true", help="skip the general-alpha side measurement")
     p.add_argument("--pool-candidates", type=int, default=12,
                    help="output pools allocated and probed before the warm-up, the fastest is kept (1 = plain allocation)")
+    p.add_argument("--rehearse-one-gpu", action="store_true", help="TEST HOOK, never a measurement: every rank uses GPU 0 "
+                   "and the collectives run over gloo, so the whole multi-rank code path of this script can be exercised "
+                   "on a one-GPU box (tests/test_gpu_configs.py); the line carries \"rehearsal_one_gpu\": true")
     p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
                    "many frames (>= --frames) but process only --frames of them")
     return p.parse_args(argv)
@@ -224,13 +227,18 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: there is no CPU fallback for the hot path")
 
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if args.rehearse_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     pkg = entry.load_package()
     # launch on torch's current stream so torch's allocator and the barrier below order with the kernels
@@ -391,6 +399,8 @@ def main(argv=None):
             "checksum": "%016x" % red["checksum"],
             "pool_placement": pool_probes,
         }
+        if args.rehearse_one_gpu:
+            line["rehearsal_one_gpu"] = True  # all ranks shared GPU 0: the value is not a measurement
         if pool_probes:
             # the first candidate is what a plain allocation gives; the kept one is the searched placement
             line["roofline"]["frac_plain_alloc"] = algo_bytes / (pool_probes[0] * 1e-3) / 1e9 / HBM_PEAK_GBS

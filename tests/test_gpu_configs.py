@@ -194,6 +194,34 @@ def test_bench_line_carries_parity_roofline_and_cpu_baseline(tmp_path):
     assert line["parity"]["max_abs_diff"] == 0
 
 
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """The code an 8-GPU run executes — self-spawned ranks, process group, sharded synthesis, table broadcast and
+    install, per-rank placement search, barriers, checksum / time reduction, rank-0 parity sample — run for real with
+    two and three ranks that share this box's one GPU (`--rehearse-one-gpu`: gloo instead of RCCL, which refuses two
+    ranks on one device; a rehearsal, not a measurement).  Frames shard by index, so the job checksum must equal the
+    one-rank checksum of the same frames, under weak and under strong scaling."""
+    root = entry.ROOT
+    common = ["--steps", "2", "--warmup", "1", "--pool-candidates", "2", "--no-cpu-baseline", "--no-ceiling",
+              "--no-side-figures", "--width", "1920", "--height", "1080"]
+
+    def run(extra):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + extra, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, (extra, r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout  # rank 0 alone prints
+        return json.loads(lines[0])
+
+    one = run(["--gpus", "1", "--frames", "12"])
+    weak = run(["--gpus", "2", "--frames", "6", "--rehearse-one-gpu"])
+    assert weak["n_gpus"] == 2 and weak["scaling"] == "weak" and weak["rehearsal_one_gpu"] and weak["parity"]["ok"]
+    assert weak["config"]["total_frames"] == 12 and weak["checksum"] == one["checksum"]
+    strong = run(["--gpus", "3", "--total-frames", "12", "--rehearse-one-gpu", "--filter", "pipeline"])
+    one_p = run(["--gpus", "1", "--total-frames", "12", "--filter", "pipeline"])
+    assert strong["n_gpus"] == 3 and strong["scaling"] == "strong" and strong["parity"]["max_abs_diff"] == 0
+    assert strong["config"]["total_frames"] == 12 and strong["checksum"] == one_p["checksum"]
+
+
 # ---- mi355_ctx_set_gauss_weights: tables the separable kernels must not touch --------------------------------------
 def test_external_tables_are_applied_as_given(ctx, pkg, oracle):
     """FAST mode + an installed table that is not w (x) w: the library must apply the 2-D table tap by tap (the
