@@ -46,6 +46,73 @@ __device__ __forceinline__ float exact_sum(const float (&g)[K][PX], int u, const
     return sum;
 }
 
+// Constant windows.  Where the image is flat the separable value sits a few 1e-6 under an integer (the table sums to
+// just under one), so EVERY pixel is flagged, and paying the 2 k^2-operation chain for all of them made flat content —
+// letterbox bars, saturated regions, graphics, the blocks of a decoded JPEG sky — the worst case (256 x 4K frames of
+// 64 x 64 flat patches: fused pipeline 2.6 TB/s against 4.9 on noise, EXACT Gaussian 1.4 against 4.8).  But the CPU path's
+// chain over a window whose k^2 values all equal c is a function of c alone: flat_chain() tabulates it once per
+// workgroup (256 floats in LDS), and flat_windows() replaces the chain by a table read for every flagged pixel whose
+// window is constant: per row, column minima / maxima over the ring (2 (K - 1) operations per column, neighbour columns
+// through DPP), per pixel a 2R + 1-column minimum / maximum and one comparison.  Called under a wave-uniform branch, and
+// only when many lanes are flagged at once (dense_flags): noise-like frames never enter it.
+template <int K>
+__device__ __forceinline__ float flat_chain(float c, const float* __restrict__ w2)
+{
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < K * K; i++)
+        sum = sum + c * w2[i];  // -ffp-contract=off: the CPU path's multiply, then its add (GaussianBlur.cpp:249-252)
+    return sum;
+}
+
+__device__ __forceinline__ bool dense_flags(uint64_t ballot)
+{
+    return __builtin_popcountll(ballot) >= 8;  // wave-uniform
+}
+
+// g = the ring exact_sum() reads (all K slots are the window's rows).  For every pixel J whose flag is up (t[J] <
+// two_delta) and whose K x K window is constant: S[J] = flat[c], the flag goes down (t[J] = 1).
+template <int K, int PX>
+__device__ __forceinline__ void flat_windows(const float (&g)[K][PX], float (&S)[PX], float (&t)[PX], float two_delta,
+                                             const float* flat)
+{
+    constexpr int R = K / 2;
+    float mn[PX + 2 * R], mx[PX + 2 * R];
+#pragma unroll
+    for (int e = 0; e < PX; e++) {
+        float a = g[0][e], b = g[0][e];
+#pragma unroll
+        for (int s = 1; s < K; s++) {
+            a = fminf(a, g[s][e]);
+            b = fmaxf(b, g[s][e]);
+        }
+        mn[R + e] = a;
+        mx[R + e] = b;
+    }
+#pragma unroll
+    for (int i = 0; i < R; i++) {
+        mn[R - 1 - i] = dppl(mn[R + PX - 1 - i]);  // column -1 - i = the left lane's column PX - 1 - i
+        mx[R - 1 - i] = dppl(mx[R + PX - 1 - i]);
+        mn[R + PX + i] = dppr(mn[R + i]);          // column PX + i = the right lane's column i
+        mx[R + PX + i] = dppr(mx[R + i]);
+    }
+#pragma unroll
+    for (int J = 0; J < PX; J++) {
+        float a = mn[J], b = mx[J];
+#pragma unroll
+        for (int c = 1; c <= 2 * R; c++) {
+            a = fminf(a, mn[J + c]);
+            b = fmaxf(b, mx[J + c]);
+        }
+        const bool is_flat = (a == b) && (t[J] < two_delta);
+        if (__builtin_amdgcn_ballot_w64(is_flat) != 0) {
+            const float val = flat[(uint32_t)a];  // a is a byte value held as a float
+            S[J] = is_flat ? val : S[J];
+            t[J] = is_flat ? 1.0f : t[J];
+        }
+    }
+}
+
 // u(x) = half an ulp of a float of magnitude <= x
 inline double half_ulp(double x)
 {

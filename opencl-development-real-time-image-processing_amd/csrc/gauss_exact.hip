@@ -47,10 +47,13 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_exact_kernel(const 
                                                                          ETables<2 * R + 1> tab)
 {
     constexpr int K = 2 * R + 1;
+    __shared__ float flat[256];  // flat[c] = the CPU path's chain over a window that is c everywhere (exact_common.hpp)
+    flat[threadIdx.x] = flat_chain<K>((float)threadIdx.x, tab.w2);
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     SlideItem it;
     if (!slide_item(plan, nstrips, h, &it))
-        return;
+        return;  // after the only barrier
     const int strip = it.strip, y0 = it.y0, nout = it.nout;
     const size_t frame = it.frame;
     const bool up = (it.band & 1) != 0;  // wave-uniform
@@ -158,7 +161,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void gauss_exact_kernel(const 
                             t[e] = __builtin_amdgcn_fractf(acc);
                         }
                         const float tmin = fminf(fminf(t[0], t[1]), fminf(t[2], t[3]));
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin < two_delta) != 0, 0)) {
+                        const uint64_t flagged = __builtin_amdgcn_ballot_w64(tmin < two_delta);
+                        if (__builtin_expect(flagged != 0, 0)) {
+                            // (k = 7 is left out: with the ring of 4 x 7 rows the extra live values push the kernel
+                            // from 198 VGPRs into scratch memory)
+                            if (R <= 2 && dense_flags(flagged)) {  // flat content: constant windows take a table read
+                                if (!stores) {           // halo and idle lanes store nothing: no exceptions on their behalf
+#pragma unroll
+                                    for (int J = 0; J < 4; J++)
+                                        t[J] = 1.0f;
+                                }
+                                flat_windows<K, 4>(g[c], S, t, two_delta, flat);
+                            }
 #define MI355_EXACT_PX(J)                                                         \
     if (__builtin_amdgcn_ballot_w64(t[J] < two_delta) != 0) {                       \
         if (up)                                                                   \

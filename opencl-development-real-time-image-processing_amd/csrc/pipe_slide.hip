@@ -62,7 +62,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
 {
     constexpr int K = 2 * R + 1;
     __shared__ uint8_t lut[256];  // lut[b] = luma(b, b, b), the reference double-precision formula
+    __shared__ float flat[256];   // flat[c] = the CPU path's chain over a window that is c everywhere (exact_common.hpp)
     lut[threadIdx.x] = (uint8_t)luma_rgb(threadIdx.x, threadIdx.x, threadIdx.x);
+    flat[threadIdx.x] = flat_chain<K>((float)threadIdx.x, tab.w2);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     const int jw = w - x_lane;  // RAGGED: position of column x = w inside this lane, if 0 <= jw <= 3
     const int q_end = min((strip + 1) * lanes_out, quads);
     const bool stores = (lane >= 1) && (q_lane < q_end);
+    const int keep_px = (lane == 0) ? 3 : ((q_lane == q_end) ? 0 : -1);  // the pixel a halo lane's neighbour reads
 
     // output rows y0 .. y0+nout-1 need blurred rows y0-1 .. y0+nout, which need gray rows y0-1-R .. y0+nout+R;
     // "arrival index" i = 0 .. nin-1 counts them in walking order (top down, or bottom up for odd bands)
@@ -202,7 +205,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                         for (int px = 0; px < 4; px++)
                             t[px] = __builtin_amdgcn_fractf(S[px]);
                         const float tmin = fminf(fminf(t[0], t[1]), fminf(t[2], t[3]));
-                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin < two_delta) != 0, 0)) {
+                        const uint64_t flagged = __builtin_amdgcn_ballot_w64(tmin < two_delta);
+                        if (__builtin_expect(flagged != 0, 0)) {
+                            if (dense_flags(flagged)) {  // flat content: constant windows take a table read
+                                if (!stores) {
+                                    // a halo lane owes its neighbour one blurred pixel, idle lanes none
+#pragma unroll
+                                    for (int J = 0; J < 4; J++)
+                                        if (J != keep_px)
+                                            t[J] = 1.0f;
+                                }
+                                flat_windows<K, 4>(g, S, t, two_delta, flat);
+                            }
                             // one wave-uniform branch per pixel position: only positions some lane flagged pay
 #define MI355_EXACT_PX(J)                                                                                  \
     if (__builtin_amdgcn_ballot_w64(t[J] < two_delta) != 0) {                                              \

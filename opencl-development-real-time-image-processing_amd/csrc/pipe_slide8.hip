@@ -47,7 +47,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
 {
     constexpr int K = 2 * R + 1;
     __shared__ uint8_t lut[256];  // lut[b] = luma(b, b, b), the reference double-precision formula
+    __shared__ float flat[256];   // flat[c] = the CPU path's chain over a window that is c everywhere (exact_common.hpp)
     lut[threadIdx.x] = (uint8_t)luma_rgb(threadIdx.x, threadIdx.x, threadIdx.x);
+    flat[threadIdx.x] = flat_chain<K>((float)threadIdx.x, tab.w2);
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
     const bool edge_strip = (strip == 0) || (8 * (strip * lanes_out + 63) > w);  // wave-uniform
     const int o_end = min((strip + 1) * lanes_out, octs);
     const bool stores = (lane >= 1) && (o_lane < o_end);
+    const int keep_px = (lane == 0) ? PX - 1 : ((o_lane == o_end) ? 0 : -1);  // the pixel a halo lane's neighbour reads
 
     const int nin = nout + 2 + 2 * R;
     const int y_first = up ? y0 + nout + R : y0 - 1 - R;
@@ -157,7 +160,18 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
                     t[px] = __builtin_amdgcn_fractf(acc);
                 }
                 const float tmin = fminf(fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), fminf(fminf(t[4], t[5]), fminf(t[6], t[7])));
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(tmin < two_delta) != 0, 0)) {
+                const uint64_t flagged = __builtin_amdgcn_ballot_w64(tmin < two_delta);
+                if (__builtin_expect(flagged != 0, 0)) {
+                    if (dense_flags(flagged)) {  // flat content: constant windows take a table read, not the chain
+                        if (!stores) {
+                            // a halo lane owes its neighbour ONE blurred pixel (the column next to the strip), idle lanes none
+#pragma unroll
+                            for (int J = 0; J < PX; J++)
+                                if (J != keep_px)
+                                    t[J] = 1.0f;
+                        }
+                        flat_windows<K, PX>(g, S, t, two_delta, flat);
+                    }
 #define MI355_EXACT_PX(J)                                                          \
     if (__builtin_amdgcn_ballot_w64(t[J] < two_delta) != 0) {                        \
         if (up)                                                                    \

@@ -29,9 +29,11 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(uint32_t* __restrict__ 
         const uint32_t f = (uint32_t)(i / per_frame);
         const uint32_t rem = (uint32_t)(i - (size_t)f * per_frame);
         const uint32_t y = rem / (uint32_t)w, x = rem - y * (uint32_t)w;
-        const uint32_t hsh = synth_hash(seed, (uint32_t)first_frame + f, y, x);
+        // mode 2: flat 64 x 64 patches (one colour per patch): frames whose windows are constant almost everywhere
+        const uint32_t hsh = (mode == 2) ? synth_hash(seed, (uint32_t)first_frame + f, y >> 6, x >> 6)
+                                         : synth_hash(seed, (uint32_t)first_frame + f, y, x);
         uint32_t px;
-        if (mode == 0) {
+        if (mode == 0 || mode == 2) {
             px = (hsh & 0x00FFFFFFu) | 0xFF000000u;
         } else {
             const int gx = (int)((x * 255u) / (uint32_t)(w > 1 ? w - 1 : 1));

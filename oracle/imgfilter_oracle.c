@@ -478,9 +478,11 @@ ORACLE_API void oracle_synth_rgba(uint8_t *out, int w, int h, int nframes, int f
         uint8_t *fr = out + (size_t)f * w * h * 4;
         for (int y = 0; y < h; y++) {
             for (int x = 0; x < w; x++) {
-                uint32_t hsh = synth_hash(seed, (uint32_t)(first_frame + f), (uint32_t)y, (uint32_t)x);
+                /* mode 2: flat 64 x 64 patches (graphics, letterbox bars, saturated regions): one colour per patch */
+                uint32_t hsh = (mode == 2) ? synth_hash(seed, (uint32_t)(first_frame + f), (uint32_t)y >> 6, (uint32_t)x >> 6)
+                                           : synth_hash(seed, (uint32_t)(first_frame + f), (uint32_t)y, (uint32_t)x);
                 uint8_t *p = fr + ((size_t)y * w + x) * 4;
-                if (mode == 0) {
+                if (mode == 0 || mode == 2) {
                     p[0] = (uint8_t)(hsh & 0xFF);
                     p[1] = (uint8_t)((hsh >> 8) & 0xFF);
                     p[2] = (uint8_t)((hsh >> 16) & 0xFF);

@@ -461,11 +461,16 @@ bad = []
 with pkg.Context(0) as ctx:
     for (n, h, w) in [(1, 2, 16), (2, 3, 24), (1, 40, 504), (2, 131, 1000), (1, 300, 1920), (1, 7, 3840), (3, 97, 496), (1, 64, 512)]:
         for k, s in ((3, 0.8), (5, 1.5)):
-            for kind in ("noise", "synth", "flat"):
+            for kind in ("noise", "synth", "flat", "patch64", "patch6"):
                 if kind == "noise":
                     x = rand_rgba(h, w, seed=h + w + k, alpha=None, n=n)
                 elif kind == "synth":
                     x = oracle.synth_rgba(w, h, n, first_frame=k, mode=1)
+                elif kind == "patch64":   # flat 64 x 64 patches: the constant-window table path (exact_common.hpp)
+                    x = oracle.synth_rgba(w, h, n, first_frame=k, mode=2)
+                elif kind == "patch6":    # 6 x 9 patches: constant and almost-constant windows side by side
+                    small = rand_rgba((h + 5) // 6, (w + 8) // 9, seed=h * w + k, alpha=255, n=n)
+                    x = np.ascontiguousarray(np.repeat(np.repeat(small, 6, axis=1), 9, axis=2)[:, :h, :w])
                 else:
                     x = np.full((n, h, w, 4), 200, np.uint8); x[:, :, w // 2:, :3] = 31
                 got = ctx.pipeline(x, k, s)
@@ -474,6 +479,45 @@ with pkg.Context(0) as ctx:
                         bad.append((n, h, w, k, kind, f))
 print(bad)
 """
+
+
+@pytest.mark.parametrize("h,w,n", [(70, 512, 2), (33, 1023, 1), (131, 250, 2), (5, 64, 1), (200, 1920, 1)])
+def test_flat_content_takes_the_table_path_and_stays_bit_exact(ctx, pkg, oracle, h, w, n):
+    """Flat content (letterbox bars, saturated regions, graphics, JPEG-blocky skies) flags every pixel of the
+    exact-by-exception kernels; constant windows then read the CPU chain's value from a 256-entry table instead of
+    evaluating it (exact_common.hpp: flat_windows).  Frames of 64 x 64 and of 6 x 9 flat patches, a two-level frame and a
+    constant one, through the fused pipeline (4-pixel kernel here, aligned and ragged widths; the 8-pixel kernel:
+    test_pipeline_eight_pixels_per_lane) and the EXACT-mode Gaussian (3- and 4-channel walks): bit-identical to the CPU
+    chain."""
+    small = rand_rgba((h + 5) // 6, (w + 8) // 9, seed=h * w, alpha=255, n=n)
+    frames = {
+        "patch64": oracle.synth_rgba(w, h, n, first_frame=3, mode=2),
+        "patch6": np.ascontiguousarray(np.repeat(np.repeat(small, 6, axis=1), 9, axis=2)[:, :h, :w]),
+        "const": np.full((n, h, w, 4), 255, np.uint8),
+    }
+    two = np.full((n, h, w, 4), 200, np.uint8)
+    two[:, :, w // 2:, :3] = 31
+    two[:, h // 2, :, 0] = 77
+    frames["two-level"] = two
+    for kind, x in frames.items():
+        for k, s in ((3, 0.8), (5, 1.5), (7, 2.0)):
+            got = ctx.pipeline(x, k, s)
+            for f in range(n):
+                assert np.array_equal(got[f], oracle.pipeline_rgba(x[f], k, s)), (kind, k, f)
+        if w % 4 == 0:
+            ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+            try:
+                for k, s in ((3, 0.8), (5, 1.5)):
+                    for alpha in (False, True):
+                        y = x.copy()
+                        if alpha:  # patchy alpha as well: the 4-channel walk, flat in all four channels
+                            y[..., 3] = np.repeat(np.repeat(rand_rgba((h + 15) // 16, (w + 15) // 16, seed=k, n=n)[..., 0], 16, axis=1),
+                                                  16, axis=2)[:, :h, :w]
+                        got = ctx.gauss(y, k, s)
+                        for f in range(n):
+                            assert np.array_equal(got[f], oracle.gauss_rgba(y[f], k, s)), (kind, k, alpha, f)
+            finally:
+                ctx.set_gauss_mode(pkg.GAUSS_FAST)
 
 
 def test_pipeline_eight_pixels_per_lane():
