@@ -71,7 +71,7 @@ def parse(argv=None):
     p.add_argument("--mode", default="fast", choices=["fast", "exact"])
     p.add_argument("--impl", default="auto", choices=["auto", "tile", "mfma", "valu"], help="kernel selection "
                    "(mi355_ctx_set_impl): auto = the library's own choice")
-    p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise, 2 = flat 64x64 patches")
+    p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise, 2 = flat 64x64 patches, 3 = gray noise (r = g = b)")
     p.add_argument("--random-alpha", action="store_true", help="overwrite the frames' alpha (255 by definition "
                    "of the synthetic frames, as after cvtColor BGR2RGBA) with noise: measures the Gaussian's "
                    "general 4-channel path instead of its opaque fast path")

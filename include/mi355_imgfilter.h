@@ -209,7 +209,8 @@ int mi355_filter_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, 
 
 /* Synthetic frames: px = hash(seed, first_frame + f, y, x), A = 255; mode 1 = smooth
  * gradient + 4-bit noise, mode 2 = flat 64 x 64 patches (constant windows: the content that sends the
- * exact-by-exception kernels down their exception path).  Bit-identical to oracle_synth_rgba. */
+ * exact-by-exception kernels down their exception path), mode 3 = gray noise (r = g = b: every pixel on the
+ * luminance's ambiguous case).  Bit-identical to oracle_synth_rgba. */
 int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes, int first_frame,
                           uint32_t seed, int mode);
 /* Order-independent 64-bit checksum of nbytes at d_buf (sum of per-word hashes mod 2^64; word i is

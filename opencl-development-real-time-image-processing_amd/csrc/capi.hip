@@ -908,7 +908,7 @@ MI355_API int mi355_pipeline_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d
 MI355_API int mi355_synth_rgba8_dev(mi355_ctx* ctx, void* d_out, int w, int h, int nframes,
                                     int first_frame, uint32_t seed, int mode)
 {
-    if (!ctx || mode < 0 || mode > 2)
+    if (!ctx || mode < 0 || mode > 3)
         return MI355_ERR_BAD_ARG;
     int rc = check_frames(d_out, d_out, w, h, nframes);
     if (rc != MI355_OK)

@@ -68,6 +68,23 @@ __device__ __forceinline__ float luma_px_fast(uint32_t px)
     return q;
 }
 
+// The ambiguous case of a GRAY pixel (r = g = b = v: S = 1000 v, always ambiguous) read from a table: gray_lut[v] =
+// luma_rgb(v, v, v), 256 bytes in LDS that a kernel fills once per workgroup (fill_gray_lut).  On colour content one pixel
+// in a thousand takes the FP64 formula; on gray content — monochrome cameras, documents, the reference's own Artemis
+// photographs — EVERY pixel did (256 x 4K frames of gray noise: Sobel 4.2 TB/s against 5.9 on colour noise, fused
+// pipeline 4.05 against 4.9).  Other ambiguous colours keep the FP64 formula.
+__device__ __forceinline__ void fill_gray_lut(uint8_t* gray_lut)  // 256 threads; the caller's __syncthreads() follows
+{
+    gray_lut[threadIdx.x] = (uint8_t)luma_rgb(threadIdx.x, threadIdx.x, threadIdx.x);
+}
+
+__device__ __forceinline__ uint32_t luma_px_ambiguous(uint32_t px, const uint8_t* gray_lut)
+{
+    if (((px ^ (px >> 8)) & 0xFFFFu) == 0u)  // r == g and g == b
+        return gray_lut[px & 0xFFu];
+    return luma_px(px);
+}
+
 // Four pixels at once: the same values, but one exception test for the whole quad (the minimum of the four
 // remainders; they are >= 0 because q never exceeds S/1000), i.e. one branch per lane-quad instead of four.
 __device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4])
@@ -86,6 +103,25 @@ __device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4])
         for (int j = 0; j < 4; j++)
             if (rem[j] == 0.0f)
                 g[j] = (float)luma_px(p[j]);
+    }
+}
+
+__device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4], const uint8_t* gray_lut)
+{
+    float rem[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t hi = __builtin_amdgcn_udot4(p[j], 0x00000201u, 0u, false);
+        const uint32_t lo = __builtin_amdgcn_udot4(p[j], 0x00724B2Bu, 0u, false);
+        const float S = (float)((hi << 8) + lo);
+        g[j] = __builtin_floorf(__builtin_fmaf(S, 0.001f, 0.0005f));
+        rem[j] = __builtin_fmaf(g[j], -1000.0f, S);  // exact: an integer in [0, 999]
+    }
+    if (fminf(fminf(rem[0], rem[1]), fminf(rem[2], rem[3])) == 0.0f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (rem[j] == 0.0f)
+                g[j] = (float)luma_px_ambiguous(p[j], gray_lut);
     }
 }
 
@@ -114,6 +150,30 @@ __device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4])
         for (int j = 0; j < 4; j++)
             if (low[j] < 1000000u)
                 q[j] = luma_px(p[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        g[j] = (float)q[j];
+}
+
+__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const uint8_t* gray_lut)
+{
+    constexpr uint32_t M = 4294968u;
+    uint32_t q[4], low[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t hi = __builtin_amdgcn_udot4(p[j], 0x00000201u, 0u, false);
+        const uint32_t lo = __builtin_amdgcn_udot4(p[j], 0x00724B2Bu, 0u, false);
+        const uint32_t S = (hi << 8) + lo;
+        __builtin_assume(S < (1u << 18));  // <= 255000: lets instruction selection take the 24-bit multiplies
+        q[j] = (uint32_t)(((uint64_t)S * M) >> 32);
+        low[j] = __umul24(S, M);
+    }
+    if (min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (low[j] < 1000000u)
+                q[j] = luma_px_ambiguous(p[j], gray_lut);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
                     p.a = p.b;
                 }
             }
-            luma_quad_int(p.a, &g[u][0]);
-            luma_quad_int(p.b, &g[u][4]);
+            luma_quad_int(p.a, &g[u][0], lut);
+            luma_quad_int(p.b, &g[u][4], lut);
             if (i >= 2 * R) {
                 // vertical pass, symmetric pair form; window = arrival rows i-2R .. i = slots (u+1+t) % K
                 float v[PX];

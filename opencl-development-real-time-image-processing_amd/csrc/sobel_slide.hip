@@ -54,8 +54,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const int quads = (w + 3) >> 2;
     const int lane = threadIdx.x & 63;
     SlideItem it;
+    __shared__ uint8_t gray_lut[256];  // luma(v, v, v): the ambiguous case of gray pixels without FP64 (common.hpp)
+    fill_gray_lut(gray_lut);
+    __syncthreads();
     if (!slide_item(plan, nstrips, h, &it))
-        return;  // (pipeline: after the only barrier)
+        return;  // after the only barrier
     const int strip = it.strip, y0 = it.y0, nout = it.nout;
     const size_t frame = it.frame;
 
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
                         p.x = p.z;  // x = w   <-  x = w-2 (lane holds pixels w-4..w-1)
                 }
             }
-            luma_quad_fast(p, L[u]);
+            luma_quad_fast(p, L[u], gray_lut);
 
             // rows i-2 (top), i-1 (middle), i (bottom) -> output row m = i - 2
             const float* t = L[(u + 1) % K];
@@ -200,8 +203,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
     constexpr int K = 3;
     const int lane = threadIdx.x & 63;
     SlideItem it;
+    __shared__ uint8_t gray_lut[256];  // luma(v, v, v): the ambiguous case of gray pixels without FP64 (common.hpp)
+    fill_gray_lut(gray_lut);
+    __syncthreads();
     if (!slide_item(plan, nstrips, h, &it))
-        return;
+        return;  // after the only barrier
     const int w = 4 * quads, y0 = it.y0, nout = it.nout, nin = nout + 2;
     const int q = it.strip * 64 + lane;
     const int q_last = min((it.strip + 1) * 64, quads) - 1;  // last quad of this strip (wave-uniform)
@@ -248,7 +254,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
             const int i = base + u;
             const Row r = qr[u];
             qr[(u + PF) % K] = load_row(i + PF);
-            luma_quad_fast(r.p, L[u]);
+            luma_quad_fast(r.p, L[u], gray_lut);
             HL[u] = luma_px_fast(r.hl);
             HR[u] = luma_px_fast(r.hr);
 

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(kThreads) void synth_kernel(uint32_t* __restrict__ 
         uint32_t px;
         if (mode == 0 || mode == 2) {
             px = (hsh & 0x00FFFFFFu) | 0xFF000000u;
+        } else if (mode == 3) {  // gray noise, r = g = b: every pixel sits on the luminance's ambiguous case S = 1000 v
+            px = (hsh & 0xFFu) * 0x00010101u | 0xFF000000u;
         } else {
             const int gx = (int)((x * 255u) / (uint32_t)(w > 1 ? w - 1 : 1));
             const int gy = (int)((y * 255u) / (uint32_t)(h > 1 ? h - 1 : 1));

@@ -486,6 +486,8 @@ ORACLE_API void oracle_synth_rgba(uint8_t *out, int w, int h, int nframes, int f
                     p[0] = (uint8_t)(hsh & 0xFF);
                     p[1] = (uint8_t)((hsh >> 8) & 0xFF);
                     p[2] = (uint8_t)((hsh >> 16) & 0xFF);
+                } else if (mode == 3) { /* gray noise, r = g = b: every pixel sits on the luminance's ambiguous case */
+                    p[0] = p[1] = p[2] = (uint8_t)(hsh & 0xFF);
                 } else {
                     int gx = (int)(((uint32_t)x * 255u) / (uint32_t)(w > 1 ? w - 1 : 1));
                     int gy = (int)(((uint32_t)y * 255u) / (uint32_t)(h > 1 ? h - 1 : 1));

@@ -670,6 +670,38 @@ def test_big_batch_kernels(ctx, pkg, oracle):
     ctx.free(d_in)
 
 
+def test_gray_content_takes_the_table_path_and_stays_bit_exact(ctx, pkg, oracle):
+    """On gray content (r = g = b: monochrome cameras, documents, the reference's Artemis photographs) every pixel sits on
+    the luminance's ambiguous case S = 1000 v; gray pixels then read luma(v, v, v) from a 256-byte table instead of
+    evaluating the FP64 formula (common.hpp: luma_px_ambiguous).  Gray noise, gray with colour specks (both branches in one
+    wave), and the 36-frame 4K batch that takes sobel_slide.hip's aligned-strip kernel: bit-identical to the CPU path."""
+    for (h, w, n) in [(9, 64, 1), (70, 1023, 2), (131, 512, 1), (300, 1920, 1)]:
+        x = oracle.synth_rgba(w, h, n, first_frame=1, mode=3)
+        speck = x.copy()
+        rng = np.random.default_rng(h * w)
+        ys, xs = rng.integers(0, h, 200), rng.integers(0, w, 200)
+        speck[0, ys, xs, :3] = rng.integers(0, 256, (200, 3), dtype=np.uint8)
+        speck[0, ys[:50], xs[:50], :3] = np.array([[0, 72, 24]], np.uint8)  # an ambiguous NON-gray colour: S = 45,000
+        for y in (x, speck):
+            sob, g1, pipe = ctx.sobel(y), ctx.gray1(y), ctx.pipeline(y, 5, 1.5)
+            for f in range(n):
+                assert np.array_equal(sob[f], oracle.sobel_rgba(y[f])), (h, w, f)
+                assert np.array_equal(g1[f], oracle.gray_rgba_1ch(y[f])), (h, w, f)
+                assert np.array_equal(pipe[f], oracle.pipeline_rgba(y[f], 5, 1.5)), (h, w, f)
+    w, h, n = 3840, 2160, 36
+    per = w * h
+    d_in, d_out = ctx.alloc(per * n * 4), ctx.alloc(per * n)
+    ctx.synth_dev(d_in, w, h, n, first_frame=0, seed=0x5EED, mode=3)
+    for filt, ref_fn in ((pkg.FILTER_SOBEL, oracle.sobel_rgba), (pkg.FILTER_PIPELINE, lambda fr: oracle.pipeline_rgba(fr, 5, 1.5))):
+        ctx.filter_dev(filt, d_in, d_out, w, h, n, 5, 1.5)
+        got = np.empty((h, w), np.uint8)
+        for f in (0, n - 1):
+            ctx.d2h(got, d_out + f * per)
+            assert np.array_equal(got, ref_fn(oracle.synth_rgba(w, h, 1, first_frame=f, mode=3)[0]))
+    ctx.free(d_out)
+    ctx.free(d_in)
+
+
 def test_sobel_stays_close_to_the_reference_opencl_kernel(ctx, oracle):
     """Secondary, tolerance-only check: the reference's own GPU kernel (RT/kernel/edge_base.cl:12-56
     + Controller::ConvertToUChar, RT/src/Controller.cpp:76-85) computes a float luminance / 255, float Sobel, clamps
