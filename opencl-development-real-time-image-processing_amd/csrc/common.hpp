@@ -106,8 +106,29 @@ __device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4])
     }
 }
 
-__device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4], const uint8_t* gray_lut)
+// gray_run: a wave-uniform hint the caller carries from row to row.  It goes up when most lanes of a row met the
+// ambiguous case (gray content does that on every pixel) and then the NEXT row first asks whether all its 256 pixels
+// are gray — one OR-tree and one ballot — and if so reads the four luminances straight from the table: no dot
+// products, no quotient, no exception branch, so gray frames cost what colour frames cost.  Colour content never raises
+// the hint and pays one scalar branch per row.
+__device__ __forceinline__ bool gray_row(const u32x4& p, float g[4], const uint8_t* gray_lut)
 {
+    const uint32_t ng = ((p.x ^ (p.x >> 8)) | (p.y ^ (p.y >> 8)) | (p.z ^ (p.z >> 8)) | (p.w ^ (p.w >> 8))) & 0xFFFFu;
+    if (__builtin_amdgcn_ballot_w64(ng != 0u) != 0)
+        return false;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        g[j] = (float)gray_lut[p[j] & 0xFFu];
+    return true;
+}
+
+__device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4], const uint8_t* gray_lut, bool& gray_run)
+{
+    if (gray_run) {  // wave-uniform
+        if (gray_row(p, g, gray_lut))
+            return;
+        gray_run = false;
+    }
     float rem[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -117,7 +138,9 @@ __device__ __forceinline__ void luma_quad_fast(const u32x4& p, float g[4], const
         g[j] = __builtin_floorf(__builtin_fmaf(S, 0.001f, 0.0005f));
         rem[j] = __builtin_fmaf(g[j], -1000.0f, S);  // exact: an integer in [0, 999]
     }
-    if (fminf(fminf(rem[0], rem[1]), fminf(rem[2], rem[3])) == 0.0f) {
+    const bool amb = fminf(fminf(rem[0], rem[1]), fminf(rem[2], rem[3])) == 0.0f;
+    gray_run = __builtin_popcountll(__builtin_amdgcn_ballot_w64(amb)) >= 48;
+    if (amb) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (rem[j] == 0.0f)
@@ -156,8 +179,13 @@ __device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4])
         g[j] = (float)q[j];
 }
 
-__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const uint8_t* gray_lut)
+__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const uint8_t* gray_lut, bool& gray_run)
 {
+    if (gray_run) {  // wave-uniform; see luma_quad_fast
+        if (gray_row(p, g, gray_lut))
+            return;
+        gray_run = false;
+    }
     constexpr uint32_t M = 4294968u;
     uint32_t q[4], low[4];
 #pragma unroll
@@ -169,7 +197,9 @@ __device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const 
         q[j] = (uint32_t)(((uint64_t)S * M) >> 32);
         low[j] = __umul24(S, M);
     }
-    if (min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u) {
+    const bool amb = min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u;
+    gray_run = __builtin_popcountll(__builtin_amdgcn_ballot_w64(amb)) >= 48;
+    if (amb) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (low[j] < 1000000u)

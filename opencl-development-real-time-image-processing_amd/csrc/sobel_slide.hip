@@ -110,6 +110,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     };
 
     constexpr int PF = 3;
+    bool gray_run = false;  // wave-uniform hint for the luminance (common.hpp: gray_row)
     u32x4 q[K];
 #pragma unroll
     for (int u = 0; u < PF; u++)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
                         p.x = p.z;  // x = w   <-  x = w-2 (lane holds pixels w-4..w-1)
                 }
             }
-            luma_quad_fast(p, L[u], gray_lut);
+            luma_quad_fast(p, L[u], gray_lut, gray_run);
 
             // rows i-2 (top), i-1 (middle), i (bottom) -> output row m = i - 2
             const float* t = L[(u + 1) % K];
@@ -240,6 +241,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
     };
 
     constexpr int PF = 3;
+    bool gray_run = false;  // wave-uniform hint for the luminance (common.hpp: gray_row)
     Row qr[K];
 #pragma unroll
     for (int u = 0; u < PF; u++)
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
             const int i = base + u;
             const Row r = qr[u];
             qr[(u + PF) % K] = load_row(i + PF);
-            luma_quad_fast(r.p, L[u], gray_lut);
+            luma_quad_fast(r.p, L[u], gray_lut, gray_run);
             HL[u] = luma_px_fast(r.hl);
             HR[u] = luma_px_fast(r.hr);
 
