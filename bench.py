@@ -72,6 +72,9 @@ def parse(argv=None):
     p.add_argument("--impl", default="auto", choices=["auto", "tile", "mfma", "valu"], help="kernel selection "
                    "(mi355_ctx_set_impl): auto = the library's own choice")
     p.add_argument("--synth-mode", type=int, default=0, help="0 = hash noise, 1 = gradient + noise, 2 = flat 64x64 patches, 3 = gray noise (r = g = b)")
+    p.add_argument("--photo", default="", help="side measurement on photographic content instead of synthetic frames: a PNG "
+                   "(e.g. tests/golden/tulips_medium640_rgb.png, tests/golden/ref_images/Artemis_medium640_rgb.png — decoded "
+                   "pixels of the reference's own test images) tiled to the frame size, every frame shifted by a few pixels")
     p.add_argument("--random-alpha", action="store_true", help="overwrite the frames' alpha (255 by definition "
                    "of the synthetic frames, as after cvtColor BGR2RGBA) with noise: measures the Gaussian's "
                    "general 4-channel path instead of its opaque fast path")
@@ -256,6 +259,16 @@ def main(argv=None):
     FA = max(F, args.alloc_frames)
     d_in = torch.empty((FA, h, w, 4), dtype=torch.uint8, device=dev)[:F]
     ctx.synth_dev(d_in.data_ptr(), w, h, F, first_frame=first_frame, seed=0x5EED, mode=args.synth_mode)
+    if args.photo:
+        from PIL import Image
+        img = np.asarray(Image.open(args.photo).convert("RGB"))
+        reps = (-(-h // img.shape[0]) + 1, -(-w // img.shape[1]) + 1, 1)
+        big = torch.from_numpy(np.ascontiguousarray(np.tile(img, reps))).to(dev)
+        for f in range(F):  # frame f = the tiling seen through a window that moves with the (global) frame index
+            oy, ox = (7 * (first_frame + f)) % img.shape[0], (13 * (first_frame + f)) % img.shape[1]
+            d_in[f, :, :, :3] = big[oy:oy + h, ox:ox + w]
+        d_in[..., 3] = 255
+        del big
     if args.random_alpha:
         d_in[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
 
@@ -379,7 +392,8 @@ def main(argv=None):
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u8 in/out, f32 accumulate" if args.filter in ("gauss", "pipeline") else "u8 in/out, f64 luminance",
-            "data": "synthetic (device-generated counter-hash frames, resident in HBM before timing)",
+            "data": ("photographic: %s tiled to the frame size, resident in HBM before timing" % os.path.basename(args.photo)) if args.photo
+                    else "synthetic (device-generated counter-hash frames, resident in HBM before timing)",
             "config": {"workload": "%s k=%d sigma=%g, %dx%d RGBA, %s, mode=%s" %
                                    (args.filter, args.k, args.sigma, w, h,
                                     ("%d frames in all" % args.total_frames) if strong else ("%d frames/GPU/step" % F),

@@ -67,7 +67,10 @@ __device__ __forceinline__ float flat_chain(float c, const float* __restrict__ w
 
 __device__ __forceinline__ bool dense_flags(uint64_t ballot)
 {
-    return __builtin_popcountll(ballot) >= 8;  // wave-uniform
+    // wave-uniform.  On noise-like frames a flagged row has ONE flagged lane (a lane-row is flagged with probability
+    // ~3e-3: three at once once in a thousand rows); a flat area a few lanes wide is worth the ~130-instruction search,
+    // which costs about two chains.
+    return __builtin_popcountll(ballot) >= 3;
 }
 
 // g = the ring exact_sum() reads (all K slots are the window's rows).  For every pixel J whose flag is up (t[J] <
