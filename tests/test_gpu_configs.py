@@ -192,6 +192,14 @@ def test_bench_line_carries_parity_roofline_and_cpu_baseline(tmp_path):
     line = json.loads(run.stdout.strip().splitlines()[-1])
     assert line["scaling"] == "strong" and line["config"]["total_frames"] == 8 and line["parity"]["ok"]
     assert line["parity"]["max_abs_diff"] == 0
+    # photographic content (the reference's Artemis image tiled to the frame size): same checker, same bar
+    photo = os.path.join(root, "tests", "golden", "ref_images", "Artemis_medium640_rgb.png")
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--filter", "pipeline", "--frames", "6", "--width", "1920",
+                          "--height", "1080", "--photo", photo, "--steps", "2", "--warmup", "1", "--pool-candidates", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["data"].startswith("photographic") and line["parity"]["ok"] and line["parity"]["max_abs_diff"] == 0
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():
