@@ -179,13 +179,11 @@ __device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4])
         g[j] = (float)q[j];
 }
 
-__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const uint8_t* gray_lut, bool& gray_run)
+// (No gray_run hint here: the fused pipeline's rows are bound by the instructions BEHIND the luminance, the all-gray row
+// path gained it nothing on gray frames, and the extra branch between the loads and their first use cost its ragged-width
+// variant 13 % — hipcc drains the memory counter at such joins.)
+__device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const uint8_t* gray_lut)
 {
-    if (gray_run) {  // wave-uniform; see luma_quad_fast
-        if (gray_row(p, g, gray_lut))
-            return;
-        gray_run = false;
-    }
     constexpr uint32_t M = 4294968u;
     uint32_t q[4], low[4];
 #pragma unroll
@@ -197,9 +195,7 @@ __device__ __forceinline__ void luma_quad_int(const u32x4& p, float g[4], const 
         q[j] = (uint32_t)(((uint64_t)S * M) >> 32);
         low[j] = __umul24(S, M);
     }
-    const bool amb = min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u;
-    gray_run = __builtin_popcountll(__builtin_amdgcn_ballot_w64(amb)) >= 48;
-    if (amb) {
+    if (min(min(low[0], low[1]), min(low[2], low[3])) < 1000000u) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
             if (low[j] < 1000000u)

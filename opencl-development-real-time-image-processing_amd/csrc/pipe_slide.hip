@@ -128,7 +128,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
     };
 
     constexpr int PF = 3;
-    bool gray_run = false;  // wave-uniform hint for the luminance (common.hpp: gray_row)
     u32x4 q[K];
 #pragma unroll
     for (int u = 0; u < PF; u++)
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void pipe_slide_kernel(
                                 p = u32x4{p.w, p.w, p.w, p.w};  // replicate column w-1
                         }
                     }
-                    luma_quad_int(p, g[u], lut, gray_run);
+                    luma_quad_int(p, g[u], lut);
                     // Stage gating with scalar branches (i, y0, nout live in SGPRs, EXEC stays full for the DPP
                     // reads): the first 2R rows of a band only fill the gray ring, the next two only fill the
                     // 3-row ring, and rows past the band's last output are never stored.

@@ -96,7 +96,6 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
     };
 
     constexpr int PF = 3;
-    bool gray_run = false;  // wave-uniform hint for the luminance (common.hpp: gray_row)
     Row8 q[K];
 #pragma unroll
     for (int u = 0; u < PF; u++)
@@ -132,8 +131,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, 4) void pipe_slide8_kernel(con
                     p.a = p.b;
                 }
             }
-            luma_quad_int(p.a, &g[u][0], lut, gray_run);
-            luma_quad_int(p.b, &g[u][4], lut, gray_run);
+            luma_quad_int(p.a, &g[u][0], lut);
+            luma_quad_int(p.b, &g[u][4], lut);
             if (i >= 2 * R) {
                 // vertical pass, symmetric pair form; window = arrival rows i-2R .. i = slots (u+1+t) % K
                 float v[PX];
