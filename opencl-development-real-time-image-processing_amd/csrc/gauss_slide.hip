@@ -222,10 +222,17 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
             lane_offset_here(in_off);
         if constexpr (RAGGED) {
             if (L.edge_strip) {  // wave-uniform
+                // only the lanes that overlap the row's ends address their pixels one by one (clamped); the others take
+                // the same unaligned 16-byte access as in interior strips (4 narrow loads for all 64 lanes made the edge
+                // strips — 2 of 5 at width 1023 — cost four times the address work)
                 u32x4 r;
+                if (L.x_lane >= 0 && L.x_lane + 3 < L.w) {
+                    r = gload_a4<u32x4>(rowp + in_off);
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    r[j] = gload<uint32_t>(rowp + L.px_off[j]);
+                    for (int j = 0; j < 4; j++)
+                        r[j] = gload<uint32_t>(rowp + L.px_off[j]);
+                }
                 return r;
             }
             // interior strip: all 4 pixels are inside the row, but the row is only 4-byte aligned
@@ -368,10 +375,10 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                     if constexpr (R <= 2)
                         lane_offset_here(out_off);
                     if constexpr (RAGGED) {
-                        if (L.edge_strip) {
+                        if (L.edge_strip && L.x_lane + 3 >= L.w) {  // the last quad of a row may be partial
 #pragma unroll
                             for (int j = 0; j < 4; j++)
-                                if (L.x_lane + j < L.w)  // the last quad of a row may be partial
+                                if (L.x_lane + j < L.w)
                                     gstore_a4<uint32_t>(rowp + out_off + 4 * j, o[j]);
                         } else {
                             gstore_a4<u32x4>(rowp + out_off, o);

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
         lane_offset_here(in_off);
         if constexpr (RAGGED) {
             u32x4 r;
-            if (edge_strip) {  // wave-uniform
+            // edge strips: only the lanes that overlap the row's ends address their pixels one by one; the others take
+            // the unaligned 16-byte access of the interior strips (gauss_slide.hip: +9 % at width 1023, +55 % at 427)
+            if (edge_strip && !(x_lane >= 0 && x_lane + 3 < w)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     r[j] = gload<uint32_t>(rowp + px_off[j]);
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
                 const auto rowp = fout + (size_t)(up ? y0 + nout - 1 - m : y0 + m) * w;
                 lane_offset_here(out_off);
                 if constexpr (RAGGED) {
-                    if (edge_strip) {
+                    if (edge_strip && x_lane + 3 >= w) {  // the last quad of a row may be partial
 #pragma unroll
                         for (int j = 0; j < 4; j++)
                             if (x_lane + j < w)
