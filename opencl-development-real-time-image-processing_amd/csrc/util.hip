@@ -109,18 +109,43 @@ __global__ __launch_bounds__(kThreads) void bgr_to_rgba_kernel(const uint8_t* __
 //                         != the integer form sobel_mag_u8, in any of the four byte positions
 __global__ __launch_bounds__(kThreads) void selftest_kernel(unsigned long long* __restrict__ acc)
 {
+    static_assert(kThreads == 256, "fill_gray_lut wants 256 threads");
+    __shared__ uint8_t gray_lut[256];
+    fill_gray_lut(gray_lut);
+    __syncthreads();
     const uint32_t stride = gridDim.x * kThreads;
     uint32_t bad_luma = 0, bad_mag = 0;
+    bool hint = false;  // the table forms carry the gray-row hint as the kernels do
     for (uint32_t c = (blockIdx.x * kThreads + threadIdx.x) * 4u; c < (1u << 24); c += stride * 4u) {
         const u32x4 p = {c | 0xFF000000u, (c + 1u) | 0x7F000000u, c + 2u, (c + 3u) | 0x01000000u};
-        float g[4], gi[4];
+        float g[4], gi[4], gt[4], git[4];
         luma_quad_fast(p, g);
         luma_quad_int(p, gi);
+        luma_quad_fast(p, gt, gray_lut, hint);  // ambiguous gray pixels by table (common.hpp)
+        luma_quad_int(p, git, gray_lut);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t want = luma_px(p[j]);
-            bad_luma += ((uint32_t)g[j] != want) + ((uint32_t)luma_px_fast(p[j]) != want) + ((uint32_t)gi[j] != want);
+            bad_luma += ((uint32_t)g[j] != want) + ((uint32_t)luma_px_fast(p[j]) != want) + ((uint32_t)gi[j] != want) +
+                        ((uint32_t)gt[j] != want) + ((uint32_t)git[j] != want);
         }
+    }
+    // all-gray wave rows: the first call raises the hint (every lane ambiguous), the second takes gray_row()
+    for (uint32_t r = 0; r < 4; r++) {
+        const uint32_t v0 = (threadIdx.x * 4u + r * 61u) & 0xFFu;
+        const u32x4 p = {v0 * 0x010101u | 0xFF000000u, ((v0 + 1u) & 0xFFu) * 0x010101u, ((v0 + 2u) & 0xFFu) * 0x010101u | 0x80000000u,
+                         ((v0 + 3u) & 0xFFu) * 0x010101u};
+        float ga[4], gb[4];
+        bool h2 = false;
+        luma_quad_fast(p, ga, gray_lut, h2);
+        const bool raised = h2;
+        luma_quad_fast(p, gb, gray_lut, h2);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t want = luma_px(p[j]);
+            bad_luma += ((uint32_t)ga[j] != want) + ((uint32_t)gb[j] != want);
+        }
+        bad_luma += raised ? 0u : 1u;
     }
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < 1021u * 1021u; i += stride) {
         const int gx = (int)(i / 1021u), gy = (int)(i % 1021u);
