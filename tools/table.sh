@@ -2,7 +2,7 @@
 # tools/table.sh — one-box table of every kernel's steady-state rate, bench.py per row
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 row() { python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling --no-side-figures "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; p=d.get('parity',{}); print('%-52s %6.0f GB/s  %5.1f %%  %8.0f Mpx/s  %6.3f ms  parity max|d| %s' % ('$*', r['achieved'], 100*r['frac'], d['value'], r['avg_launch_ms'], p.get('max_abs_diff')))"; }
-python3 $ROOT/bench.py --no-cpu-baseline --no-parity --filter gray 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('box: stream-copy ceiling (mi355_stream_copy_dev) %.0f GB/s' % d['roofline']['copy_ceiling_GBs'])"
+python3 $ROOT/bench.py --no-cpu-baseline --no-parity --filter gray 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('box: streaming ceiling %.0f GB/s (%s)' % (d['roofline']['copy_ceiling_GBs'], d['roofline']['copy_ceiling_kernel']))"
 row --filter gray
 row --filter gray1
 row --filter gauss --k 3
