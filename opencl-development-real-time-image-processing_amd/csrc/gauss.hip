@@ -57,8 +57,14 @@ hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
     case GaussKernel::Mfma:
         // the register-operand skeleton (gauss_mfma_reg.hip) is the faster one; the LDS-staged kernel stays as its
         // A/B partner (tuning build: MI355_MFMA_LDS=1) and for frames of 2 GiB and more
-        if (!tune_env("MI355_MFMA_LDS") && gauss_mfma_reg_supported(d_in, d_out, w, h, coef))
+        if (!tune_env("MI355_MFMA_LDS") && gauss_mfma_reg_supported(d_in, d_out, w, h, coef)) {
+            // gauss_mfma_dma.hip = the same kernel with its input tiles staged by LDS-DMA: same bits, same speed
+            // (-1 .. +2 % over five launch shapes, profiles/r02_mfma_ablations.txt), so the simpler one stays the default
+            // and the DMA kernel its A/B partner (tuning build: MI355_MFMA_DMA=1)
+            if (tune_env("MI355_MFMA_DMA"))
+                return launch_gauss_mfma_dma(stream, d_in, d_out, w, h, nframes, coef);
             return launch_gauss_mfma_reg(stream, d_in, d_out, w, h, nframes, coef);
+        }
         return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Exact: return launch_gauss_exact(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Slide: return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);

@@ -58,6 +58,10 @@ hipError_t launch_gauss_exact(hipStream_t stream, const uint8_t* d_in, uint8_t* 
 // matrix-core kernel (gauss_mfma.hip): any odd k <= 17, width % 4 == 0, 16-byte aligned buffers, FAST arithmetic
 bool gauss_mfma_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
 bool gauss_mfma_reg_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
+// gauss_mfma_dma.hip: the same kernel with LDS-DMA input staging (same conditions as gauss_mfma_reg_supported)
+bool gauss_mfma_dma_supported(const uint8_t* d_in, const uint8_t* d_out, int w, int h, const GaussCoef& coef);
+hipError_t launch_gauss_mfma_dma(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
+                                 const GaussCoef& coef);
 hipError_t launch_gauss_mfma_reg(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
                                  const GaussCoef& coef);
 hipError_t launch_gauss_mfma(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h, int nframes,
