@@ -528,6 +528,36 @@ def test_flat_content_takes_the_table_path_and_stays_bit_exact(ctx, pkg, oracle,
                 ctx.set_gauss_mode(pkg.GAUSS_FAST)
 
 
+def test_data_dependent_paths_on_seeded_random_shapes_and_content(ctx, pkg, oracle):
+    """The table paths are data-dependent (constant windows, gray pixels, gray rows): 24 seeded random cases — shape, blocky
+    content with random block sizes (1 x 1 = noise ... 16 x 16), a random share of gray blocks, k in {3, 5, 7} — through
+    the pipeline, Sobel, gray and the EXACT Gaussian, whole frames against the CPU path."""
+    rng = np.random.default_rng(20240)
+    for case in range(24):
+        h, w = int(rng.integers(2, 220)), int(rng.integers(4, 900))
+        if case % 3 == 0:
+            w = (w + 7) // 8 * 8
+        by, bx = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+        small = rng.integers(0, 256, ((h + by - 1) // by, (w + bx - 1) // bx, 4), dtype=np.uint8)
+        gray_share = float(rng.choice([0.0, 0.3, 1.0]))
+        mask = rng.random(small.shape[:2]) < gray_share
+        small[mask, 1] = small[mask, 0]
+        small[mask, 2] = small[mask, 0]
+        small[..., 3] = 255
+        x = np.ascontiguousarray(np.repeat(np.repeat(small, by, axis=0), bx, axis=1)[:h, :w])
+        k, sg = [(3, 0.8), (5, 1.5), (7, 2.0)][case % 3]
+        tag = (case, h, w, by, bx, gray_share, k)
+        assert np.array_equal(ctx.pipeline(x, k, sg), oracle.pipeline_rgba(x, k, sg)), tag
+        assert np.array_equal(ctx.sobel(x), oracle.sobel_rgba(x)), tag
+        assert np.array_equal(ctx.gray1(x), oracle.gray_rgba_1ch(x)), tag
+        if w % 4 == 0 and k <= 5:
+            ctx.set_gauss_mode(pkg.GAUSS_EXACT)
+            try:
+                assert np.array_equal(ctx.gauss(x, k, sg), oracle.gauss_rgba(x, k, sg)), tag
+            finally:
+                ctx.set_gauss_mode(pkg.GAUSS_FAST)
+
+
 def test_pipeline_eight_pixels_per_lane():
     """AUTO gives k = 5 launches of >= 10^9 pixels to pipe_slide8.hip (config 5's 512-frame launch above: same checksum
     as the 4-pixel kernel's 8 x 64 frames, frames equal to the oracle).  Here the tuning build forces it
