@@ -51,9 +51,13 @@ def main():
                 path = os.path.join(REF, "src", app, "results", "%s_100_%s_sorted_results.csv" % (osname, series))
                 for row in csv.DictReader(open(path), skipinitialspace=True):
                     name = os.path.splitext(os.path.basename(row["Image"].strip()))[0]
-                    out.setdefault(key, {}).setdefault(osname, {})[name] = {
-                        "resolution": row["Resolution"].strip(), "Error_MAE": row["Error_MAE"].strip(),
-                        "source": os.path.relpath(path, REF)}
+                    entry = {"resolution": row["Resolution"].strip(), "Error_MAE": row["Error_MAE"].strip(),
+                             "source": os.path.relpath(path, REF)}
+                    for col in ("Num_Iterations", "avg_CPU_Time_ms", "avg_OpenCL_Time_ms", "avg_OpenCL_kernel_ms",
+                                "avg_OpenCL_kernel_write_ms", "avg_OpenCL_kernel_read_ms", "avg_OpenCL_kernel_operation_ms"):
+                        if col in row:  # the published timings, for tools/harness.py's side-by-side columns
+                            entry[col] = row[col].strip()
+                    out.setdefault(key, {}).setdefault(osname, {})[name] = entry
     json.dump(out, open(os.path.join(HERE, "published_mae.json"), "w"), indent=1, sort_keys=True)
     os.makedirs(os.path.join(HERE, "ref_images"), exist_ok=True)
     for n in COMMITTED:

@@ -89,6 +89,27 @@ def main():
         for r in rows:
             f.write(", ".join(str(v) for v in r) + ", %g, %g\n" % (r[4] / r[5], r[4] / r[9]))
     print(open(derived).read())
+    # <out>_vs_published.csv: where an image is one of the reference's own test images (tests/golden/ref_images/<name>_rgb.png
+    # = decoded pixels of images/<name>.jpg), the row the reference published for it on its Linux box
+    # (src/*/results/Linux_100_*_sorted_results.csv, committed as tests/golden/published_mae.json) beside this run's
+    pub_path = os.path.join(ROOT, "tests", "golden", "published_mae.json")
+    if os.path.exists(pub_path):
+        import json
+        pub = json.load(open(pub_path))[{"GRAYSCALE": "gray", "EDGE": "sobel", "GAUSSIAN": "gauss"}[args.method]]["Linux"]
+        side = os.path.splitext(args.out)[0] + "_vs_published.csv"
+        cols = ["avg_CPU_Time_ms", "avg_OpenCL_Time_ms", "avg_OpenCL_kernel_operation_ms", "Error_MAE"]
+        with open(side, "w", newline="") as f:
+            f.write("Image, Resolution, " + ", ".join("here_" + c for c in cols) + ", " +
+                    ", ".join("reference_Linux_" + c for c in cols) + ", end_to_end_ratio_reference_over_here\n")
+            for r in rows:
+                name = {"tulips_medium640_rgb": "Tulips_medium640"}.get(os.path.splitext(r[1])[0],
+                                                                      os.path.splitext(r[1])[0].replace("_rgb", ""))
+                if name not in pub or pub[name]["resolution"] != r[2]:
+                    continue
+                here = [r[4], r[5], r[9], r[10]]
+                ref = [float(pub[name][c]) for c in cols]
+                f.write("%s, %s, " % (name, r[2]) + ", ".join("%g" % v for v in here + ref) + ", %g\n" % (ref[1] / here[1]))
+        print(open(side).read())
 
 
 if __name__ == "__main__":
