@@ -88,6 +88,9 @@ def parse(argv=None):
     p.add_argument("--rehearse-one-gpu", action="store_true", help="TEST HOOK, never a measurement: every rank uses GPU 0 "
                    "and the collectives run over gloo, so the whole multi-rank code path of this script can be exercised "
                    "on a one-GPU box (tests/test_gpu_configs.py); the line carries \"rehearsal_one_gpu\": true")
+    p.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (backend nccl = RCCL) even "
+                   "with one rank, so the process group, the table broadcast, both all-reduces, the per-rank gather and the "
+                   "barriers run on RCCL on a one-GPU box (tests/test_gpu_configs.py); the measurement is unchanged")
     p.add_argument("--alloc-frames", type=int, default=0, help="experiment: size the device buffers for this "
                    "many frames (>= --frames) but process only --frames of them")
     return p.parse_args(argv)
@@ -126,6 +129,26 @@ def reduce_results(dist, elapsed, launch_ms, checksum, npixels, device):
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return {"t_max": float(t[0]), "ms_max": float(t[1]),
             "checksum": (int(c[0]) + (int(c[1]) << 32)) & 0xFFFFFFFFFFFFFFFF, "pixels": int(c[2])}
+
+
+def gather_per_rank(dist, rank, world, record, device):
+    """Every rank's scalars, gathered on all ranks: [{rank, first_frame, frames, avg_launch_ms, wall_s, probe_first_ms,
+    probe_kept_ms, pool_candidates}].  The job's line carries the max over ranks; this makes skew between ranks visible."""
+    keys = ["first_frame", "frames", "avg_launch_ms", "wall_s", "probe_first_ms", "probe_kept_ms", "pool_candidates"]
+    if dist is None:
+        return [dict({"rank": rank}, **{k: record[k] for k in keys})]
+    import torch
+    mine = torch.tensor([float(record[k]) for k in keys], dtype=torch.float64, device=device)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    out = []
+    for r, t in enumerate(got):
+        v = t.cpu().tolist()
+        d = {"rank": r}
+        for k, x in zip(keys, v):
+            d[k] = int(x) if k in ("first_frame", "frames", "pool_candidates") else x
+        out.append(d)
+    return out
 
 
 def checksum_index_base(first_frame, w, h, out_bpp):
@@ -169,6 +192,10 @@ def spawn_ranks(n, argv):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
+        # RCCL's intra-node transport shares device buffers between the rank processes through HIP IPC handles; this
+        # pool's host driver supports only the dmabuf flavour of IPC, and with the legacy mode left on
+        # hipIpcGetMemHandle fails with "invalid argument" (the image exports the variable for the same reason; it is
+        # repeated here so that a caller's scrubbed environment cannot lose it).  No effect on a single rank.
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
     rcs = [p.wait() for p in procs]
@@ -235,9 +262,13 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist  # noqa: F811
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.rehearse_one_gpu:
             dist.init_process_group(backend="gloo")
         else:
@@ -368,6 +399,10 @@ def main(argv=None):
     checksum = ctx.checksum_dev(d_out.data_ptr(), d_out.numel(),
                                 index_base=checksum_index_base(first_frame, w, h, out_bpp))
     red = reduce_results(dist, elapsed, avg_launch_ms, checksum, F * w * h, dev)
+    per_rank = gather_per_rank(dist, rank, world, {
+        "first_frame": first_frame, "frames": F, "avg_launch_ms": avg_launch_ms, "wall_s": elapsed,
+        "probe_first_ms": pool_probes[0] if pool_probes else 0.0,
+        "probe_kept_ms": min(pool_probes) if pool_probes else 0.0, "pool_candidates": len(pool_probes)}, dev)
 
     rc = 0
     if rank == 0:
@@ -422,6 +457,10 @@ def main(argv=None):
                          "kernel": "see profiles/ (rocprofv3 --kernel-trace --stats of this command)"},
             "checksum": "%016x" % red["checksum"],
             "pool_placement": pool_probes,
+            "per_rank": per_rank,
+            "collectives": ("none (single process)" if dist is None else
+                            "%s: broadcast(table), all_reduce(max time), all_reduce(sum checksum/pixels), all_gather(per_rank), barrier"
+                            % dist.get_backend()),
         }
         if args.rehearse_one_gpu:
             line["rehearsal_one_gpu"] = True  # all ranks shared GPU 0: the value is not a measurement
@@ -449,6 +488,18 @@ def main(argv=None):
             line["general_path"] = {"what": "same launch on frames with random alpha (no opaque fast path), 12 launches",
                                     "avg_launch_ms": ms2, "achieved": algo_bytes / (ms2 * 1e-3) / 1e9,
                                     "frac": algo_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            # constant alpha that is not 255 (an overlay at half opacity): the 3-channel pass with the table byte
+            d_in2[..., 3] = 128
+            for _ in range(4):
+                launch(d_in2.data_ptr(), d_out.data_ptr())
+            torch.cuda.synchronize(dev)
+            ctx.timer_begin()
+            for _ in range(12):
+                launch(d_in2.data_ptr(), d_out.data_ptr())
+            ms3 = ctx.timer_end() / 12
+            line["const_alpha_path"] = {"what": "same launch on frames with alpha = 128 everywhere (constant-alpha fast path), 12 launches",
+                                        "avg_launch_ms": ms3, "achieved": algo_bytes / (ms3 * 1e-3) / 1e9,
+                                        "frac": algo_bytes / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del d_in2
             torch.cuda.empty_cache()
             step()  # d_out holds the opaque frames' result again for the parity sample below

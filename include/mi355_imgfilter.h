@@ -111,7 +111,10 @@ int mi355_bgr_to_rgba8_dev(mi355_ctx* ctx, const void* d_bgr, void* d_rgba, int 
  * is not w (x) w for one non-negative vector w up to float rounding (a non-separable or asymmetric table, negative
  * lobes), the separable FAST kernels do not apply and every call with that key runs the tap-by-tap (EXACT
  * arithmetic) kernel, as the reference kernel would (RT/kernel/gaussian_base.cl:23-44).  Non-finite entries are
- * rejected (MI355_ERR_BAD_ARG).  A context keeps the 16 most recently used tables. */
+ * rejected (MI355_ERR_BAD_ARG).  Installed tables are never evicted (at most 64 per context, one more is
+ * MI355_ERR_BAD_ARG); of the tables the library generates itself a context keeps the 16 most recently used.  The
+ * first call with a new (k, sigma) key — and mi355_ctx_set_gauss_weights itself — synchronises the context's stream
+ * (allocation + blocking upload of the table); calls with a cached key do not. */
 int mi355_gauss_weights(int k, float sigma, float* out_k2);
 int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, const float* w_k2);
 
@@ -193,8 +196,11 @@ int mi355_host_free(mi355_ctx* ctx, void* h_ptr);
 /* ---- device-resident calls -----------------------------------------------------------------
  * d_in / d_out are device pointers on the context's GPU holding nframes tightly packed frames;
  * the call enqueues the kernel(s) on the context's stream and returns without synchronising.
- * [d_in, d_in + 4*w*h*nframes) and the output range must not overlap: every kernel reads neighbouring rows and
- * halo pixels, so an in-place call is rejected with MI355_ERR_BAD_ARG instead of returning corrupted pixels.
+ * [d_in, d_in + 4*w*h*nframes) and the output range must not overlap: the stencil filters (Gaussian, Sobel,
+ * pipeline) read neighbouring rows and halo pixels that another wave may already have overwritten, and the
+ * grayscale kernels, although pointwise, are compiled with non-aliasing (__restrict__) pointers and non-temporal
+ * accesses — so an in-place or overlapping call is rejected with MI355_ERR_BAD_ARG, for every filter, instead of
+ * returning corrupted pixels.  (The reference never aliases them either: two clCreateBuffer objects per call.)
  * These are what a caller that already owns device memory (torch, a capture pipeline) binds, and
  * what the roofline measurement times (no PCIe in the timed region). */
 int mi355_gray_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);

@@ -22,12 +22,18 @@ struct CoefEntry {
     int k;
     uint32_t sigma_bits;
     GaussCoef coef;
-    float* d_buf;  // [k*k w2d][k w1d]
+    float* d_buf;  // [k*k w2d][k w1d][256 constant-alpha bytes << 24, as uint32]
     std::vector<float> h_tab;  // host copy of the same block (its heap storage stays put when entries move)
     uint64_t last_use;
+    bool installed;  // came through mi355_ctx_set_gauss_weights: never evicted (it cannot be regenerated)
 };
 
-constexpr size_t kMaxCoefEntries = 16;  // distinct (k, sigma) tables kept per context; least recently used goes
+// Distinct GENERATED (k, sigma) tables kept per context; the least recently used one goes.  Tables a caller installed
+// (mi355_ctx_set_gauss_weights: a box filter, a non-separable table, the bytes rank 0 broadcast) are kept outside
+// this cap and are never evicted — a miss would silently regenerate the default Gaussian under the same key; at most
+// kMaxInstalledCoefs of them per context, one more is MI355_ERR_BAD_ARG.
+constexpr size_t kMaxCoefEntries = 16;
+constexpr size_t kMaxInstalledCoefs = 64;
 
 }  // namespace
 
@@ -168,19 +174,26 @@ bool separable_factor(int k, const float* w2d, float* w1d)
     return dev <= 1.0e-6 * wmax;
 }
 
-int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const GaussCoef** out)
+// First use of a (k, sigma) key — and a call that evicts — synchronises the context's stream and makes blocking
+// allocations / copies; every later call with a cached key does not (include/mi355_imgfilter.h says so).
+int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, bool installed, const GaussCoef** out)
 {
     CoefEntry* slot = nullptr;
-    for (auto& e : ctx->coefs)
+    size_t n_generated = 0, n_installed = 0;
+    for (auto& e : ctx->coefs) {
         if (e.k == k && e.sigma_bits == fbits(sigma))
             slot = &e;
+        (e.installed ? n_installed : n_generated)++;
+    }
     if (!slot) {
-        if (ctx->coefs.size() >= kMaxCoefEntries) {
-            // evict the least recently used table; a kernel still in flight may be reading it
+        if (installed && n_installed >= kMaxInstalledCoefs)
+            return MI355_ERR_BAD_ARG;
+        if (!installed && n_generated >= kMaxCoefEntries) {
+            // evict the least recently used GENERATED table; a kernel still in flight may be reading it
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            size_t lru = 0;
-            for (size_t i = 1; i < ctx->coefs.size(); i++)
-                if (ctx->coefs[i].last_use < ctx->coefs[lru].last_use)
+            size_t lru = ctx->coefs.size();
+            for (size_t i = 0; i < ctx->coefs.size(); i++)
+                if (!ctx->coefs[i].installed && (lru == ctx->coefs.size() || ctx->coefs[i].last_use < ctx->coefs[lru].last_use))
                     lru = i;
             (void)hipFree(ctx->coefs[lru].d_buf);
             ctx->coefs.erase(ctx->coefs.begin() + (long)lru);
@@ -188,14 +201,19 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
         CoefEntry e{};
         e.k = k;
         e.sigma_bits = fbits(sigma);
-        HIP_TRY(ctx, hipMalloc((void**)&e.d_buf, sizeof(float) * (size_t)(k * k + k)));
+        HIP_TRY(ctx, hipMalloc((void**)&e.d_buf, sizeof(float) * (size_t)(k * k + k + 256)));
         ctx->coefs.push_back(e);
         slot = &ctx->coefs.back();
     }
     slot->last_use = ++ctx->coef_clock;
-    std::vector<float> host((size_t)k * k + k);
+    slot->installed = slot->installed || installed;
+    std::vector<float> host((size_t)k * k + k + 256);
     std::memcpy(host.data(), w2d, sizeof(float) * (size_t)k * k);
     const bool separable = separable_factor(k, w2d, host.data() + (size_t)k * k);
+    uint32_t alpha_tab[256];
+    for (uint32_t a = 0; a < 256; a++)
+        alpha_tab[a] = gauss_const_alpha(host.data() + (size_t)k * k, k, a) << 24;
+    std::memcpy(host.data() + (size_t)k * k + k, alpha_tab, sizeof(alpha_tab));
     // blocking copy from pageable memory: the table is live on the device when this returns
     const hipError_t ce = hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice);
     if (ce != hipSuccess) {
@@ -209,6 +227,8 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, const Gau
     slot->coef.separable = separable;
     slot->coef.d_w2d = slot->d_buf;
     slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
+    slot->coef.d_alpha_tab = reinterpret_cast<const uint32_t*>(slot->d_buf + (size_t)k * k + k);
+    std::memcpy(slot->coef.h_alpha_tab, alpha_tab, sizeof(alpha_tab));
     std::memset(slot->coef.h_w1d, 0, sizeof(slot->coef.h_w1d));
     std::memcpy(slot->coef.h_w1d, host.data() + (size_t)k * k, sizeof(float) * k);
     slot->h_tab = host;
@@ -228,7 +248,7 @@ int get_coef(mi355_ctx* ctx, int k, float sigma, const GaussCoef** out)
         }
     std::vector<float> w((size_t)k * k);
     gen_weights(k, sigma, w.data());
-    return install_coef(ctx, k, sigma, w.data(), out);
+    return install_coef(ctx, k, sigma, w.data(), false, out);
 }
 
 int ensure(mi355_ctx* ctx, void** p, size_t* cap, size_t need)
@@ -284,9 +304,10 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
     if (rgba_out && (reinterpret_cast<uintptr_t>(d_out) & 3u))
         return MI355_ERR_BAD_ARG;
     {
-        // every kernel reads neighbouring rows / halo pixels of what another wave may already have overwritten:
-        // in-place and overlapping calls are rejected, not run (the reference never aliases them either: two
-        // clCreateBuffer objects per call, RT/src/Controller.cpp:234-244)
+        // the stencil kernels read neighbouring rows / halo pixels of what another wave may already have overwritten,
+        // and the (pointwise) grayscale kernels are compiled for non-aliasing pointers (__restrict__, non-temporal
+        // accesses): in-place and overlapping calls are rejected, not run, for every filter (the reference never
+        // aliases them either: two clCreateBuffer objects per call, RT/src/Controller.cpp:234-244)
         const int bpp = mi355_filter_out_bpp(filter);
         if (bpp < 0)
             return MI355_ERR_BAD_ARG;
@@ -674,7 +695,7 @@ MI355_API int mi355_ctx_set_gauss_weights(mi355_ctx* ctx, int k, float sigma, co
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // a kernel still in flight may be reading the previous table of this key
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return install_coef(ctx, k, sigma, w_k2, nullptr);
+    return install_coef(ctx, k, sigma, w_k2, true, nullptr);
 }
 
 MI355_API int mi355_filter_out_bpp(int filter)

@@ -3,7 +3,22 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+#include <cmath>
+
 namespace mi355 {
+
+uint32_t gauss_const_alpha(const float* w1d, int k, uint32_t a)
+{
+    const float av = (float)a;
+    float vc = w1d[0] * av;
+    for (int t = 1; t < k; t++)
+        vc = std::fmaf(w1d[t], av, vc);  // finished vertical sum
+    float hc = w1d[0] * vc;
+    for (int t = 1; t < k; t++)
+        hc = std::fmaf(w1d[t], vc, hc);
+    hc = hc < 0.0f ? 0.0f : (hc > 255.0f ? 255.0f : hc);  // uchar(std::clamp(.)) of the CPU path
+    return (uint32_t)hc;
+}
 
 namespace {
 

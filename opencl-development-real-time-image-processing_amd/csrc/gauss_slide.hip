@@ -18,9 +18,11 @@
 //    (wave_shr:1 / wave_shl:1) — no LDS, no barrier, no shuffle instruction.
 //  * clamp-to-edge: rows by clamping the (wave-uniform) row index; columns by replicating the edge
 //    pixel into the halo lane at load time, so the arithmetic itself has no border cases.
-//  * opaque frames (every A = 255, what cv::cvtColor produces): a band is first run on 3 channels with
-//    the constant alpha result `alpha_hi` patched in; a ballot over the loaded alphas aborts the pass
-//    and the band is redone on 4 channels, so the output never depends on which pass produced it.
+//  * constant alpha (every A = 255 is what cv::cvtColor produces; mattes and overlays are piecewise constant): a
+//    band is first run on 3 channels; while the K rows of a window carry ONE alpha value A over the whole strip, the
+//    blurred alpha is the constant byte alpha_tab[A] (the canonical chains on an all-A window, evaluated by the
+//    host).  A row with mixed alphas, or a window that spans two values, aborts the pass and the band is redone on
+//    4 channels, so the output never depends on which pass produced it.
 //  * RAGGED instantiation: any width and any 4-byte-aligned pointer (unaligned 16-byte interior loads,
 //    per-pixel clamped loads and predicated narrow stores in the two edge strips).
 // Algorithmic bytes: 8 B/px.  Extra traffic: halo lanes (2/62 of the loads, L2/MALL hits) and 2R
@@ -202,16 +204,34 @@ struct SlideLane {
     int x_lane, w;        // first pixel of the lane (may be < 0 or >= w), image width
 };
 
+// Does any of the wave's 256 pixels of this row carry an alpha other than `lo >> 24`?  mn / mx = the lane's
+// smallest / largest pixel DWORD: alpha is the top byte, so they carry the lane's smallest / largest alpha.
+__device__ __forceinline__ bool alpha_row_differs(uint32_t mn, uint32_t mx, uint32_t lo)
+{
+    return __builtin_amdgcn_ballot_w64((mn < lo) | (mx > (lo | 0x00FFFFFFu))) != 0;
+}
+
+// Return codes of a pass over a band
+constexpr int kBandDone = 0;         // every output row stored
+constexpr int kBandAbortFirst = 1;   // NCH = 3 only: the band's FIRST input row has mixed alphas; q[0..PF-1] still hold
+                                     // the first PF rows, so the 4-channel pass starts from them without re-loading
+constexpr int kBandAbort = 2;        // NCH = 3 only: aborted further down; the rows stored so far are correct
+
 // One pass over the band with NCH channels computed per pixel.  NCH = 4: the general path.  NCH = 3: the
-// opaque fast path — alpha is not computed, every output gets the constant byte alpha_hi; each loaded row is
-// tested (one ballot over all 64 lanes, halo included) and the pass returns false at the first alpha != 255,
-// before that row has contributed anything: the rows stored so far are correct, and the caller redoes the band
-// with NCH = 4.
+// constant-alpha fast path — alpha is not computed; while the last K rows carry one alpha value A over all 64 lanes
+// (halo included) every output gets the constant byte alpha_tab[A] (one min3/max3 pair and one ballot per row; the
+// value changes through a scalar branch and one s_load).  A row with mixed alphas, or an output row whose window
+// spans two values, ends the pass before that row has stored anything: the rows stored so far are correct, and
+// the caller redoes the band with NCH = 4.
 template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP>
-__device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi)
+__device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi,
+                                                const uint32_t* __restrict__ alpha_tab, u32x4 (&q)[2 * R + 1],
+                                                bool preloaded)
 {
     constexpr int K = 2 * R + 1;
     uint32_t in_off = L.in_off, out_off = L.out_off;
+    uint32_t cur_lo = 0xFF000000u;  // alpha value (<< 24) the rows seen last carry; alpha_hi = alpha_tab[cur_lo >> 24]
+    int run = 0;                    // how many consecutive rows, the current one included, carry it
     auto load_row = [&](int i) -> u32x4 {
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed); an UP band
         // walks from its bottom-most input row to its top-most one
@@ -246,10 +266,11 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
     // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
     // only PF of the K slots are live at a time (PF x 1 KiB in flight per wave)
     constexpr int PF = (K < 3) ? K : 3;
-    u32x4 q[K];
+    if (!preloaded) {  // wave-uniform
 #pragma unroll
-    for (int u = 0; u < PF; u++)
-        q[u] = load_row(u);
+        for (int u = 0; u < PF; u++)
+            q[u] = load_row(u);
+    }
 
     // k <= 7: ring of the last K input rows, converted to float once (row i lives in slot i % K, static after
     // unrolling); the vertical sums of an output row are formed when its window is complete — in either walking
@@ -278,9 +299,16 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
                 }
             }
             if constexpr (NCH == 3) {
-                const uint32_t a4 = p.x & p.y & p.z & p.w;
-                if (__builtin_amdgcn_ballot_w64((a4 >> 24) != 0xFFu) != 0)  // wave-uniform
-                    return false;
+                const uint32_t mn = min(min(min(p.x, p.y), p.z), p.w), mx = max(max(max(p.x, p.y), p.z), p.w);
+                if (alpha_row_differs(mn, mx, cur_lo)) {  // wave-uniform, rare: the alpha value changes here
+                    const uint32_t a_new = __builtin_amdgcn_readfirstlane(mx) & 0xFF000000u;
+                    if (alpha_row_differs(mn, mx, a_new))
+                        return (i == 0 && PF < K) ? kBandAbortFirst : kBandAbort;  // (k = 3: q[0] already holds row 3)
+                    cur_lo = a_new;
+                    alpha_hi = __builtin_amdgcn_readfirstlane(alpha_tab[a_new >> 24]);
+                    run = 0;
+                }
+                run++;
             }
             if constexpr (kRing) {
 #pragma unroll
@@ -311,6 +339,10 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
             // the horizontal pass and the store with a scalar branch (m and nout live in SGPRs, so EXEC
             // stays full inside, which the DPP reads of the horizontal pass require)
             if (m >= 0 && m < L.nout) {
+                if constexpr (NCH == 3) {
+                    if (run < K)  // the window spans two alpha values: its blurred alpha is not a constant
+                        return kBandAbort;
+                }
                 // vertical pass in the canonical order, top tap first: a DOWN band holds the window oldest row
                 // = top row (slot u+1 ... slot u), an UP band newest row = top row (slot u, u-1, ...) — a static
                 // permutation of the same multiply-add chain, so both directions give the same bits
@@ -390,7 +422,7 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
             }
         }
     }
-    return true;
+    return kBandDone;
 }
 
 // MODE 0: one kernel, opaque pass then (if an alpha != 255 turns up) the general pass — k = 3, 5, where both fit
@@ -401,7 +433,8 @@ __device__ __forceinline__ bool gauss_slide_band(const SlideLane& L, const float
 template <int R, bool CLAMP, bool RAGGED, int MODE>
 __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1) void gauss_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
-    BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi, uint32_t* __restrict__ flags)
+    BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi, const uint32_t* __restrict__ alpha_tab,
+    uint32_t* __restrict__ flags)
 {
     const int quads = (w + 3) >> 2;  // RAGGED: the last quad of a row may hold fewer than 4 pixels
     constexpr int K = 2 * R + 1;
@@ -457,23 +490,27 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
     // each needs from the other) at the same moment and the second reader hits L2 (sobel_slide.hip does the
     // same; measured there: HBM reads -12 %).  Wave-uniform: two instantiations of the band code.
     const bool up = (it.band & 1) != 0;
-    auto run = [&](auto nch) -> bool {
+    u32x4 q[K];  // the prefetch ring of input rows: shared by the two passes (kBandAbortFirst)
+    auto run = [&](auto nch, bool preloaded) -> int {
         constexpr int NCH = decltype(nch)::value;
         if constexpr (R <= 3) {  // (the k = 9 form walks down only)
             if (up)
-                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true>(L, wv, alpha_hi);
+                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true>(L, wv, alpha_hi, alpha_tab, q, preloaded);
         }
-        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false>(L, wv, alpha_hi);
+        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false>(L, wv, alpha_hi, alpha_tab, q, preloaded);
     };
     if constexpr (MODE == 0) {
-        if (!run(std::integral_constant<int, 3>{}))
-            run(std::integral_constant<int, 4>{});
+        // frames whose alpha varies from pixel to pixel fail the first row's test: the 4-channel pass then starts
+        // from the rows already in flight (no second start-up per band)
+        const int code = run(std::integral_constant<int, 3>{}, false);
+        if (code != kBandDone)
+            run(std::integral_constant<int, 4>{}, code == kBandAbortFirst);
     } else if constexpr (MODE == 3) {
-        const bool done = run(std::integral_constant<int, 3>{});
+        const int code = run(std::integral_constant<int, 3>{}, false);
         if (lane == 0)
-            flags[it.work] = done ? 0u : 1u;
+            flags[it.work] = code == kBandDone ? 0u : 1u;
     } else {
-        run(std::integral_constant<int, 4>{});
+        run(std::integral_constant<int, 4>{}, false);
     }
 }
 
@@ -515,22 +552,16 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     for (int j = 0; j < K; j++)
         wsum += (double)coef.h_w1d[j];
     const bool clamp = !(255.0 * wsum * wsum * 1.0001 < 256.0);  // externally installed tables may overflow
-    // constant alpha byte of the opaque fast path: the canonical chains on an all-255 channel, in float
-    uint32_t alpha_hi;
-    {
-        float vc = wts.w[0] * 255.0f;
-        for (int t = 1; t < K; t++)
-            vc = std::fmaf(wts.w[t], 255.0f, vc);  // finished vertical sum
-        float hc = wts.w[0] * vc;
-        for (int t = 1; t < K; t++)
-            hc = std::fmaf(wts.w[t], vc, hc);
-        hc = hc < 0.0f ? 0.0f : (hc > 255.0f ? 255.0f : hc);  // uchar(std::clamp(.)) of the CPU path
-        alpha_hi = (uint32_t)hc << 24;
-    }
+    // constant alpha bytes of the fast path: the canonical chains on an all-A channel, evaluated by the host when
+    // the table was installed (kernels.hpp: gauss_const_alpha); A = 255, the usual case, travels by value
+    if (!coef.d_alpha_tab)
+        return hipErrorInvalidValue;
+    const uint32_t alpha_hi = coef.h_alpha_tab[255];
+    const uint32_t* alpha_tab = coef.d_alpha_tab;
     const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
 #define MI355_LAUNCH1(CL, RG, MD)                                                                               \
     hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG, MD>), grid, block, 0, stream, d_in, d_out, w, h, nstrips, \
-                       lanes_out, plan, wts, alpha_hi, d_flags)
+                       lanes_out, plan, wts, alpha_hi, alpha_tab, d_flags)
 #define MI355_LAUNCH(CL, RG)        \
     do {                            \
         if constexpr (kSplit) {     \

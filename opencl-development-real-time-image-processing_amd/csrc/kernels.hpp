@@ -20,7 +20,17 @@ struct GaussCoef {
     // may stand in for the 2-D table.  Externally installed tables that are not (mi355_ctx_set_gauss_weights) are
     // applied tap by tap by the tiled kernels, as the reference kernel applies them (RT/kernel/gaussian_base.cl:23-44).
     bool separable;
+    // alpha_tab[A] = (the FAST kernels' output byte for a channel whose whole window holds A) << 24: the canonical
+    // separable chains on an all-A window, evaluated on the host with the same float operations
+    // (gauss_const_alpha).  The constant-alpha fast path of the sliding-window kernels reads it.
+    const uint32_t* d_alpha_tab;
+    uint32_t h_alpha_tab[256];
 };
+
+// The FAST arithmetic's result for one channel of a pixel whose k x k window holds the value `a` everywhere:
+// v = w[0]*a; v = fma(w[j], a, v) down the column, o = w[0]*v; o = fma(w[t], v, o) along the row,
+// uchar(std::clamp(o, 0, 255)) — the kernels' own chain, so the byte is the one they would have computed.
+uint32_t gauss_const_alpha(const float* w1d, int k, uint32_t a);
 
 hipError_t launch_gray(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int w, int h,
                        int nframes, bool one_channel);

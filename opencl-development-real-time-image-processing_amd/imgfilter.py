@@ -58,12 +58,15 @@ def declared_symbols():
 _lib = None
 
 
-def load_library():
+def load_library(path=None):
+    """The product library (cached).  `path`: another build of the same library, bound the same way and NOT cached —
+    several builds can live in one process (tools/abx.py: same-process A/B timing on the same buffers)."""
     global _lib
-    if _lib is not None:
+    if path is None and _lib is not None:
         return _lib
+    other = path is not None
     # MI355_IMGFILTER_LIB: another build of the same library (A/B timing of kernel changes, tools/ab.sh)
-    path = os.environ.get("MI355_IMGFILTER_LIB", _LIB)
+    path = path or os.environ.get("MI355_IMGFILTER_LIB", _LIB)
     if not os.path.exists(path):
         raise Mi355Error("load_library", -1, "%s is missing: run __graft_entry__.build()" % path)
     lib = ctypes.CDLL(path)
@@ -127,7 +130,8 @@ def load_library():
     lib.mi355_strerror.restype = ctypes.c_char_p
     lib.mi355_build_info.argtypes = []
     lib.mi355_build_info.restype = ctypes.c_char_p
-    _lib = lib
+    if not other:
+        _lib = lib
     return lib
 
 
@@ -165,8 +169,8 @@ def device_count():
 class Context:
     """One GPU + one HIP stream + pooled buffers + cached coefficient tables."""
 
-    def __init__(self, device=0, stream=None):
-        self._lib = load_library()
+    def __init__(self, device=0, stream=None, lib=None):
+        self._lib = lib if lib is not None else load_library()
         self._h = _vp()
         if stream is None:
             rc = self._lib.mi355_ctx_create(int(device), ctypes.byref(self._h))

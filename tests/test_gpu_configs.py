@@ -230,6 +230,34 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert strong["config"]["total_frames"] == 12 and strong["checksum"] == one_p["checksum"]
 
 
+def test_bench_rccl_branch_with_one_rank():
+    """bench.py's RCCL branch, for real, on this box's one GPU: `--force-dist` with a torchrun-style environment
+    (set here, before the child starts: no re-exec of a GPU process) makes init_process_group("nccl", device_id=...),
+    the device-tensor broadcast of the coefficient table, both all-reduces, the per-rank all-gather and the barriers
+    execute on RCCL with world size 1.  Same frames, same kernel: the checksum equals the plain run's."""
+    import bench
+    root = entry.ROOT
+    common = ["--steps", "2", "--warmup", "1", "--pool-candidates", "2", "--no-cpu-baseline", "--no-ceiling",
+              "--no-side-figures", "--width", "1920", "--height", "1080", "--frames", "8", "--gpus", "1"]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(bench.free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common + ["--force-dist"], capture_output=True,
+                       text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert line["collectives"].startswith("nccl"), line["collectives"]
+    assert line["n_gpus"] == 1 and line["parity"]["ok"]
+    assert len(line["per_rank"]) == 1 and line["per_rank"][0]["rank"] == 0 and line["per_rank"][0]["frames"] == 8
+    assert abs(line["per_rank"][0]["avg_launch_ms"] - line["roofline"]["avg_launch_ms"]) < 1e-9
+    assert line["per_rank"][0]["pool_candidates"] == 2
+    plain = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True,
+                           timeout=900)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    pl = json.loads([ln for ln in plain.stdout.strip().splitlines() if ln.startswith("{")][0])
+    assert pl["collectives"].startswith("none") and pl["checksum"] == line["checksum"]
+
+
 # ---- mi355_ctx_set_gauss_weights: tables the separable kernels must not touch --------------------------------------
 def test_external_tables_are_applied_as_given(ctx, pkg, oracle):
     """FAST mode + an installed table that is not w (x) w: the library must apply the 2-D table tap by tap (the
@@ -263,6 +291,51 @@ def test_external_tables_are_applied_as_given(ctx, pkg, oracle):
         ctx.set_gauss_weights(k, 9.0, bad)
     # the generated key is untouched by all of the above
     assert _absdiff(ctx.gauss(img, 5, 1.5), oracle.gauss_rgba(img, 5, 1.5)).max() <= 1
+
+
+@pytest.mark.parametrize("k", [5, 9])
+def test_asymmetric_separable_factor_keeps_its_orientation(ctx, pkg, oracle, k):
+    """A rank-1 table u (x) u with an ASYMMETRIC u passes separable_factor() and goes to the FAST separable kernels:
+    gauss_slide (IMPL_VALU), the matrix-core kernel (IMPL_MFMA: its banded B operand indexes the taps backwards) and
+    whatever AUTO picks must all apply the taps in the table's orientation (correlation, as GaussianBlur.cpp:243-256
+    does), also in bands that walk upward.  The fused pipeline's sliding-window kernels need a symmetric factor, so it
+    must take the tiled path."""
+    u = np.array([0.05, 0.15, 0.4, 0.25, 0.15] if k == 5 else [0.02, 0.03, 0.05, 0.1, 0.3, 0.2, 0.15, 0.1, 0.05], np.float32)
+    table = np.outer(u, u).astype(np.float32)
+    sigma = 11.0 + k
+    ctx.set_gauss_mode(pkg.GAUSS_FAST)
+    ctx.set_gauss_weights(k, sigma, table)
+    frames = rand_rgba(260, 256, seed=77 + k, alpha=None, n=2)   # several bands per strip (odd ones walk up)
+    frames[1, ..., 3] = 255
+    ref = np.stack([oracle.gauss_rgba(f, k, weights=table) for f in frames])
+    for impl in (pkg.IMPL_AUTO, pkg.IMPL_VALU, pkg.IMPL_MFMA, pkg.IMPL_TILE):
+        ctx.set_impl(impl)
+        assert _absdiff(ctx.gauss(frames, k, sigma), ref).max() <= 1, impl
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.pipeline(frames, k, sigma)
+    ctx.set_impl(pkg.IMPL_AUTO)
+    assert np.array_equal(ctx.pipeline(frames, k, sigma), tiled)
+
+
+def test_installed_tables_survive_the_cache_bound(pkg, oracle):
+    """An installed table cannot be regenerated, so it is never evicted: after 17 other keys the installed key still gives
+    the installed table (a miss would silently compute the default Gaussian for that sigma)."""
+    img = rand_rgba(24, 40, seed=5)
+    v = np.array([0.05, 0.1, 0.7, 0.1, 0.05], np.float32)
+    box = np.outer(v, v).astype(np.float32)     # a peaked table under a sigma whose own Gaussian is nearly flat
+    with pkg.Context(0) as c:
+        c.set_gauss_weights(5, 8.0, box)
+        want = c.gauss(img, 5, 8.0)
+        assert _absdiff(want, oracle.gauss_rgba(img, 5, weights=box)).max() <= 1
+        assert _absdiff(want, oracle.gauss_rgba(img, 5, 8.0)).max() > 8      # the default table differs visibly
+        for i in range(20):
+            c.gauss(img, 5, 0.7 + 0.05 * i)
+        assert np.array_equal(c.gauss(img, 5, 8.0), want)
+        # the cap on installed tables is an explicit error, not an eviction
+        with pytest.raises(pkg.Mi355Error):
+            for i in range(70):
+                c.set_gauss_weights(3, 20.0 + i, np.full((3, 3), 1.0 / 9, np.float32))
+        assert np.array_equal(c.gauss(img, 5, 8.0), want)
 
 
 def test_coefficient_cache_is_bounded(ctx, pkg, oracle):

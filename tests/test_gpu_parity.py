@@ -202,6 +202,59 @@ def test_gauss_opaque_fast_path_and_its_fallback(ctx, pkg, oracle, k, sigma):
     assert np.array_equal(ctx.gauss(noisy, k, sigma), tiled)
 
 
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (7, 2.0), (9, 2.5)])
+def test_gauss_constant_and_piecewise_constant_alpha(ctx, pkg, oracle, k, sigma):
+    """The 3-channel pass also serves alpha that is constant but not 255, and alpha that is piecewise constant (a
+    matte: regions of different values): while the K rows of a window carry one value A over the whole strip the
+    output alpha is the host-evaluated byte of an all-A window; rows with mixed alphas and windows that span two values
+    send the band to the 4-channel pass.  Whatever the route, the bytes are the tiled kernel's (which computes alpha
+    like any other channel), and within 1 LSB of the CPU path."""
+    h, w = 300, 512
+    base = oracle.synth_rgba(w, h, 1, first_frame=k + 40, mode=0)[0]
+    cases = {}
+    for a in (0, 1, 128, 200, 254):
+        img = base.copy()
+        img[..., 3] = a
+        cases["const %d" % a] = img
+    img = base.copy()
+    img[h // 2:, :, 3] = 128                 # horizontal edge: changes inside a band, between bands, at a band boundary
+    cases["top 255 / bottom 128"] = img
+    img = base.copy()
+    img[:24, :, 3] = 7                       # exactly the first k=5 band
+    img[24:25, :, 3] = 9                     # one row
+    img[200:, :, 3] = 0
+    cases["stripes"] = img
+    img = base.copy()
+    img[:, :240, 3] = 33                     # vertical edge on a strip boundary (60 lanes x 4 px)
+    cases["left 33 / right 255 at x=240"] = img
+    img = base.copy()
+    img[:, :243, 3] = 33                     # vertical edge inside a strip
+    cases["left 33 / right 255 at x=243"] = img
+    img = base.copy()
+    img[100:200, 100:300, 3] = 64            # a block
+    img[120:130, 120:130, 3] = 255           # with a hole
+    cases["block"] = img
+    img = base.copy()
+    img[..., 3] = (np.arange(h)[:, None] // 3 + np.zeros((1, w), int)).astype(np.uint8)   # a new value every 3 rows
+    cases["ramp by rows"] = img
+    for name, img in cases.items():
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        ctx.set_impl(pkg.IMPL_TILE)
+        tiled = ctx.gauss(img, k, sigma)
+        ctx.set_impl(pkg.IMPL_VALU)
+        slide = ctx.gauss(img, k, sigma)
+        assert np.array_equal(slide, tiled), name
+        ref = oracle.gauss_rgba(img, k, sigma)
+        assert np.abs(slide.astype(np.int16) - ref.astype(np.int16)).max() <= 1, name
+    # a batch: frames with different constants, one mixed
+    frames = np.stack([cases["const 128"], cases["const 0"], cases["block"], base])
+    ctx.set_impl(pkg.IMPL_TILE)
+    tiled = ctx.gauss(frames, k, sigma)
+    ctx.set_impl(pkg.IMPL_VALU)
+    assert np.array_equal(ctx.gauss(frames, k, sigma), tiled)
+    ctx.set_impl(pkg.IMPL_AUTO)
+
+
 @pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5), (9, 2.5)])
 @pytest.mark.parametrize("h,w", [(1, 1), (2, 3), (7, 5), (75, 75), (40, 249), (33, 251), (64, 253), (131, 501),
                                  (300, 1023), (6, 3841)])

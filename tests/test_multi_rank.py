@@ -36,6 +36,11 @@ def _worker(rank, world, port, out_dir, frames_per_gpu, total_frames):
             np.array([red["checksum"], int(red["t_max"] * 10), int(red["ms_max"] * 100), red["pixels"], ck, first, n],
                      dtype=np.uint64))
     np.save(os.path.join(out_dir, "table%d.npy" % rank), table)
+    per = bench.gather_per_rank(dist, rank, world, {
+        "first_frame": first, "frames": n, "avg_launch_ms": 0.25 + rank, "wall_s": 0.5 + rank,
+        "probe_first_ms": 1.0 + rank, "probe_kept_ms": 0.75 + rank, "pool_candidates": 3 + rank}, torch.device("cpu"))
+    import json
+    json.dump(per, open(os.path.join(out_dir, "per_rank%d.json" % rank), "w"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -54,6 +59,13 @@ def test_two_ranks_shard_frames_and_agree(tmp_path, oracle, pkg, frames_per_gpu,
     assert r0[3] == r1[3] == nframes * W * H
     # contiguous, disjoint, complete frame ranges
     assert (int(r0[5]), int(r1[5])) == (0, int(r0[6])) and int(r0[6]) + int(r1[6]) == nframes
+    # the per-rank records (what makes skew visible in the line): identical on both ranks, one entry per rank
+    import json
+    p0, p1 = json.load(open(tmp_path / "per_rank0.json")), json.load(open(tmp_path / "per_rank1.json"))
+    assert p0 == p1 and [d["rank"] for d in p0] == [0, 1]
+    assert [d["avg_launch_ms"] for d in p0] == [0.25, 1.25] and [d["pool_candidates"] for d in p0] == [3, 4]
+    assert [(d["first_frame"], d["frames"]) for d in p0] == [(int(r0[5]), int(r0[6])), (int(r1[5]), int(r1[6]))]
+    assert bench.gather_per_rank(None, 0, 1, dict(p0[0]), None) == [p0[0]]
     t0, t1 = np.load(tmp_path / "table0.npy"), np.load(tmp_path / "table1.npy")
     assert np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
     assert np.array_equal(t0.view(np.uint32), oracle.gauss_weights(K, SIGMA).view(np.uint32))
