@@ -259,6 +259,44 @@ int mi355_copy_d2h(mi355_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes
 int mi355_timer_begin(mi355_ctx* ctx);
 int mi355_timer_end(mi355_ctx* ctx, float* elapsed_ms);
 
+/* ---- device group: one batch sharded over several GPUs (SURVEY.md §8b "Threading", §8e) -----------------------------
+ * The reference owns one queue on one device (RT/src/ProgramHandler.cpp:108) and has nothing to match; this is the
+ * product form of what BASELINE.json's north_star calls the batched-frame mode: independent frames, contiguous
+ * frame ranges per GPU, no pixel ever crosses GPUs, no collective.
+ *
+ * A group = one mi355_ctx + one host worker thread per member.  `devices` lists the HIP device ordinal of each
+ * member (NULL = 0 .. ndev-1); an ordinal may repeat (two members then share that GPU on two streams — how the
+ * one-GPU tests run it).  Member m of an n-member group owns the frames mi355_group_shard(m, n, nframes) names:
+ * base = nframes / n, the first nframes % n members take one extra, ranges contiguous in member order (the same
+ * split bench.py's shard_range makes over ranks).
+ *
+ *   mi355_group_filter_batched  host buffers, nframes frames back to back in `rgba` / `out`: every member streams its
+ *                               range through its own mi355_filter_stream (H2D / kernel / D2H overlapped), all
+ *                               members at once; returns when all are done.  elapsed_ms (may be NULL): wall time.
+ *   mi355_group_filter_dev      device-resident: d_in[m] / d_out[m] are pointers on member m's GPU holding
+ *                               nframes[m] frames (0 = member idle); every member launches on its own stream and
+ *                               synchronises it; returns when all are done.
+ * Gaussian coefficients: a table for (k, sigma) is generated ONCE on the host (mi355_gauss_weights) and the same bytes
+ * are installed on every member before the first call that uses the key; mi355_group_set_gauss_weights installs a
+ * caller's table on every member.  Mode / impl / input-format setters apply to every member.
+ * Status: MI355_OK, or the first failing member's code in member order (mi355_group_member_status gives each
+ * member's code of the last call).  One call at a time per group (calls are serialised internally). */
+typedef struct mi355_group mi355_group;
+int mi355_group_create(int ndev, const int* devices, mi355_group** out);
+int mi355_group_destroy(mi355_group* g);
+int mi355_group_size(mi355_group* g, int* ndev);
+int mi355_group_member_ctx(mi355_group* g, int member, mi355_ctx** ctx); /* borrowed; for alloc / copies / checksums */
+int mi355_group_member_status(mi355_group* g, int member);
+int mi355_group_shard(int member, int nmembers, int nframes, int* first_frame, int* count); /* pure host function */
+int mi355_group_set_gauss_mode(mi355_group* g, int mode);
+int mi355_group_set_impl(mi355_group* g, int impl);
+int mi355_group_set_input_format(mi355_group* g, int format);
+int mi355_group_set_gauss_weights(mi355_group* g, int k, float sigma, const float* w_k2);
+int mi355_group_filter_batched(mi355_group* g, int filter, const uint8_t* rgba, uint8_t* out, int w, int h,
+                               int nframes, int k, float sigma, double* elapsed_ms);
+int mi355_group_filter_dev(mi355_group* g, int filter, const void* const* d_in, void* const* d_out, int w, int h,
+                           const int* nframes, int k, float sigma);
+
 /* Library build info: "gfx950;<git-or-date>" */
 const char* mi355_build_info(void);
 

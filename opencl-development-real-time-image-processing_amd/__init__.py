@@ -19,11 +19,13 @@ from .imgfilter import (  # noqa: F401
     IMPL_TILE,
     IMPL_VALU,
     Context,
+    Group,
     Mi355Error,
     build_library,
     declared_symbols,
     gauss_weights,
     gauss_weights_image2d,
+    group_shard,
     library_path,
     load_library,
 )

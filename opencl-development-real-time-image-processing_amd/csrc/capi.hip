@@ -1151,6 +1151,23 @@ MI355_API int mi355_timer_end(mi355_ctx* ctx, float* elapsed_ms)
     return MI355_OK;
 }
 
+}  // extern "C"
+
+// group.hip installs the table it generated once on every member through this (hidden) hook: same path as a table
+// the context generated itself — evictable, outside the cap on caller-installed tables.
+int mi355_internal_install_generated(mi355_ctx* ctx, int k, float sigma, const float* w_k2)
+{
+    if (!ctx || !w_k2 || !valid_k(k) || !valid_sigma(sigma))
+        return MI355_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (auto& e : ctx->coefs)
+        if (e.k == k && e.sigma_bits == fbits(sigma))
+            return MI355_OK;  // already there (generated or installed by the caller: the caller's table wins)
+    return install_coef(ctx, k, sigma, w_k2, false, nullptr);
+}
+
+extern "C" {
+
 MI355_API const char* mi355_build_info(void) { return "gfx950;" __DATE__ " " __TIME__; }
 
 }  // extern "C"

@@ -16,8 +16,25 @@
 // OpenCL compiler may contract a*b+c, so the reference itself is only defined up to that); division and square root
 // correctly rounded.  The luminance is the exception: the reference published what ITS device computed — the eight
 // Error_MAE values of src/Grayscale/results/Windows_100_*_sorted_results.csv come from this kernel, and exactly one
-// contraction pattern reproduces all eight to the last digit (tests/test_published_mae.py) — so that pattern is used.  oracle_image2d_* is the CPU twin.  No shipped application takes this path (all set
-// BYPASS_IMAGE_SUPPORT = true), so the kernels are plain one-thread-per-pixel code: correctness, not bandwidth.
+// contraction pattern reproduces all eight to the last digit (tests/test_published_mae.py) — so that pattern is used.
+// oracle_image2d_* is the CPU twin.  No shipped application takes this path (all set BYPASS_IMAGE_SUPPORT = true) and
+// the host shim reports CL_DEVICE_IMAGE_SUPPORT = CL_FALSE unless the host opts in (host/src/cl_shim.cpp).
+//
+// Kernels (round 3: the one-thread-per-pixel restatements of the .cl files — k^2 global loads per pixel — are now only
+// the fallback for shapes the fast ones do not take):
+//   image2d_gauss_tile_kernel  one workgroup per 64 x 16 output tile; the tile + halo is staged ONCE in LDS as
+//                              normalised float4 texels (byte / 255.0f evaluated once per staged texel instead of once
+//                              per tap; border colour 0 written for texels outside the image), the table in LDS; a
+//                              thread owns 4 adjacent outputs and, per window row, pulls the 4 + 2*half texels it
+//                              needs into registers once (k = 17: 20 ds_read_b128 for 68 taps).  Per output the taps
+//                              accumulate ky-outer / kx-inner with separate multiply and add, as the .cl loop does.
+//                              Any width / height; k <= 25 (LDS); one 16-byte store per thread.
+//   image2d_gray_vec_kernel    16 B per lane (4 texels), the 256 possible byte / 255.0f values from an LDS table.
+//   image2d_sobel_vec_kernel   4 outputs per lane from 3 x 16 B row loads + 6 neighbour dwords (all but one row hit
+//                              L1 / L2), red channel through the same table; widths that are multiples of 4.
+// Algorithmic bytes: gray / Sobel 5 B/px, Gaussian 8 B/px.  Bound: the Gaussian by FP32 issue (2 k^2 operations per
+// channel per pixel: the .cl loop is not separable — zero border + truncated table), gray / Sobel by the PCIe copies
+// around them (the entry point is the per-frame host call, mi355_image2d_rgba8).
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -106,6 +123,176 @@ __global__ __launch_bounds__(kThreads) void image2d_sobel_kernel(const uint32_t*
     out[i] = (uint8_t)(mag * 255.0f);
 }
 
+// ---- the fast forms ---------------------------------------------------------------------------------------------------
+constexpr int kTileW = 64, kTileH = 16;   // outputs per workgroup: 256 threads x 4 adjacent outputs
+constexpr int kImgMaxFastK = 25;          // (64 + 24) x (16 + 24) float4 texels = 55 KiB of LDS
+
+// texel (x, y) of the image as read_imagef returns it under CLK_ADDRESS_CLAMP: channel / 255.0f, (0,0,0,0) outside
+__device__ __forceinline__ f32x4 read_texel(const uint32_t* __restrict__ img, int w, int h, int x, int y)
+{
+    if (x < 0 || x >= w || y < 0 || y >= h)
+        return f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const uint32_t p = img[(size_t)y * w + x];
+    return f32x4{unorm8(p & 0xFFu), unorm8((p >> 8) & 0xFFu), unorm8((p >> 16) & 0xFFu), unorm8(p >> 24)};
+}
+
+template <int HALF>
+__global__ __launch_bounds__(kThreads) void image2d_gauss_tile_kernel(const uint32_t* __restrict__ in,
+                                                                      uint32_t* __restrict__ out, int w, int h,
+                                                                      int tiles_x, int tiles_y,
+                                                                      const float* __restrict__ table)
+{
+    constexpr int K = 2 * HALF + 1;
+    constexpr int SW = kTileW + 2 * HALF, SH = kTileH + 2 * HALF;  // staged tile
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    f32x4* tile = reinterpret_cast<f32x4*>(smem_raw);              // [SH][SW]
+    float* wt = reinterpret_cast<float*>(tile + SW * SH);          // [K*K]
+
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);         // neighbouring tiles (shared halo) on one XCD
+    const int tx = (int)(blk % (uint32_t)tiles_x);
+    const int ty = (int)((blk / (uint32_t)tiles_x) % (uint32_t)tiles_y);
+    const size_t f = blk / ((uint32_t)tiles_x * (uint32_t)tiles_y);
+    const uint32_t* img = in + f * (size_t)w * h;
+    uint32_t* oimg = out + f * (size_t)w * h;
+    const int x0 = tx * kTileW, y0 = ty * kTileH;
+
+    for (int i = threadIdx.x; i < K * K; i += kThreads)
+        wt[i] = table[i];
+    for (int i = threadIdx.x; i < SW * SH; i += kThreads) {
+        const int sy = i / SW, sx = i - sy * SW;
+        tile[i] = read_texel(img, w, h, x0 + sx - HALF, y0 + sy - HALF);
+    }
+    __syncthreads();
+
+    const int row = threadIdx.x >> 4, q = threadIdx.x & 15;       // 16 rows x 16 quads
+    f32x4 acc[4] = {};
+    for (int ky = 0; ky < K; ky++) {
+        const f32x4* srow = tile + (row + ky) * SW + 4 * q;
+        f32x4 px[4 + 2 * HALF];
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * HALF; j++)
+            px[j] = srow[j];
+        const float* wrow = wt + ky * K;
+#pragma unroll
+        for (int kx = 0; kx < K; kx++) {
+            const float wv = wrow[kx];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                // sum += pixel * weight per channel: one multiply, one add (-ffp-contract=off), source order
+                acc[o].x = acc[o].x + wv * px[o + kx].x;
+                acc[o].y = acc[o].y + wv * px[o + kx].y;
+                acc[o].z = acc[o].z + wv * px[o + kx].z;
+                acc[o].w = acc[o].w + wv * px[o + kx].w;
+            }
+        }
+    }
+    const int oy = y0 + row, ox = x0 + 4 * q;
+    if (oy >= h || ox >= w)
+        return;
+    uint32_t o4[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++)
+        o4[o] = to_unorm8(acc[o].x) | (to_unorm8(acc[o].y) << 8) | (to_unorm8(acc[o].z) << 16) | (to_unorm8(acc[o].w) << 24);
+    uint32_t* dst = oimg + (size_t)oy * w + ox;
+    if (ox + 3 < w && ((reinterpret_cast<uintptr_t>(dst) & 15u) == 0)) {
+        *reinterpret_cast<u32x4*>(dst) = u32x4{o4[0], o4[1], o4[2], o4[3]};
+    } else {
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+            if (ox + o < w)
+                dst[o] = o4[o];
+    }
+}
+
+// byte / 255.0f for all 256 bytes, once per workgroup (256 threads; the caller's __syncthreads() follows)
+__device__ __forceinline__ void fill_unorm_lut(float* lut) { lut[threadIdx.x] = unorm8(threadIdx.x); }
+
+__global__ __launch_bounds__(kThreads) void image2d_gray_vec_kernel(const u32x4* __restrict__ in, uint32_t* __restrict__ out,
+                                                                    size_t nquads)
+{
+    __shared__ float lut[256];
+    fill_unorm_lut(lut);
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * kThreads;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquads; i += stride) {
+        const u32x4 p = __builtin_nontemporal_load(&in[i]);
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float x = lut[p[j] & 0xFFu], y = lut[(p[j] >> 8) & 0xFFu], z = lut[(p[j] >> 16) & 0xFFu];
+            const float gray = __builtin_fmaf(0.114f, z, __builtin_fmaf(0.299f, x, 0.587f * y));
+            o |= ((uint32_t)(gray * 255.0f) & 0xFFu) << (8 * j);
+        }
+        __builtin_nontemporal_store(o, &out[i]);
+    }
+}
+
+// w % 4 == 0, 16-byte aligned frames: a lane owns 4 adjacent outputs of one row
+__global__ __launch_bounds__(kThreads) void image2d_sobel_vec_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                                     int w, int h, size_t nquads)
+{
+    __shared__ float lut[256];
+    fill_unorm_lut(lut);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= nquads)
+        return;
+    const int qw = w >> 2;
+    const size_t fq = (size_t)qw * h;
+    const size_t f = i / fq;
+    const int y = (int)((i % fq) / qw), x = 4 * (int)(i % qw);
+    const uint32_t* img = in + f * (size_t)w * h;
+    uint32_t o = 0;
+    if (y >= 1 && y < h - 1) {
+        float r[3][6];  // red channel of texels x-1 .. x+4 on rows y-1 .. y+1 (texels outside the row: never used)
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++) {
+            const uint32_t* rowp = img + (size_t)(y + dy - 1) * w;
+            const u32x4 p = *reinterpret_cast<const u32x4*>(rowp + x);
+            r[dy][0] = lut[(x > 0 ? rowp[x - 1] : 0u) & 0xFFu];
+            r[dy][1] = lut[p.x & 0xFFu];
+            r[dy][2] = lut[p.y & 0xFFu];
+            r[dy][3] = lut[p.z & 0xFFu];
+            r[dy][4] = lut[p.w & 0xFFu];
+            r[dy][5] = lut[(x + 4 < w ? rowp[x + 4] : 0u) & 0xFFu];
+        }
+        const float sx[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
+        const float sy[3][3] = {{-1.f, -2.f, -1.f}, {0.f, 0.f, 0.f}, {1.f, 2.f, 1.f}};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (x + j < 1 || x + j >= w - 1)
+                continue;  // border column: never written by the reference kernel -> 0
+            float gx = 0.0f, gy = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    gx = gx + r[ky][j + kx] * sx[ky][kx];
+                    gy = gy + r[ky][j + kx] * sy[ky][kx];
+                }
+            float mag = __builtin_sqrtf(gx * gx + gy * gy);
+            mag = fminf(fmaxf(mag, 0.0f), 1.0f);
+            o |= ((uint32_t)(mag * 255.0f) & 0xFFu) << (8 * j);
+        }
+    }
+    out[i] = o;
+}
+
+template <int HALF>
+hipError_t launch_gauss_tile_image(hipStream_t stream, const uint32_t* in, uint32_t* out, int w, int h, int nframes,
+                                   const float* d_table)
+{
+    constexpr int K = 2 * HALF + 1;
+    const int tiles_x = (w + kTileW - 1) / kTileW, tiles_y = (h + kTileH - 1) / kTileH;
+    const size_t blocks = (size_t)tiles_x * tiles_y * nframes;
+    if (blocks > 0x7FFFFFFFull)
+        return hipErrorInvalidValue;
+    const size_t lds = sizeof(f32x4) * (size_t)(kTileW + 2 * HALF) * (kTileH + 2 * HALF) + sizeof(float) * K * K;
+    hipLaunchKernelGGL((image2d_gauss_tile_kernel<HALF>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, in, out, w,
+                       h, tiles_x, tiles_y, d_table);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 // filter: 0 gray (out = w*h bytes), 2 gauss (out = w*h*4 bytes, d_table = k*k floats on the device), 3 sobel (w*h bytes)
@@ -117,6 +304,40 @@ hipError_t launch_image2d(hipStream_t stream, int filter, const uint8_t* d_in, u
     if (blocks > 0x7FFFFFFFull)
         return hipErrorInvalidValue;
     const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in);
+    const bool in16 = (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0, out4 = (reinterpret_cast<uintptr_t>(d_out) & 3u) == 0;
+    // the per-pixel kernels below stay as the fallback (MI355_IMAGE2D_PLAIN=1 in the tuning build forces them: the A/B
+    // partner and the test that both forms give the same bytes)
+    const bool plain = tune_env("MI355_IMAGE2D_PLAIN") != nullptr;
+    if (!plain && filter == 0 && in16 && out4 && (npx & 3) == 0) {
+        const size_t nquads = npx / 4, want = (nquads + kThreads - 1) / kThreads;
+        hipLaunchKernelGGL(image2d_gray_vec_kernel, dim3((unsigned)(want > (1u << 20) ? (1u << 20) : want)), dim3(kThreads), 0,
+                           stream, reinterpret_cast<const u32x4*>(d_in), reinterpret_cast<uint32_t*>(d_out), nquads);
+        return hipGetLastError();
+    }
+    if (!plain && filter == 3 && in16 && out4 && (w & 3) == 0 && h >= 1) {
+        const size_t nquads = npx / 4;
+        hipLaunchKernelGGL(image2d_sobel_vec_kernel, dim3((unsigned)((nquads + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+                           stream, in, reinterpret_cast<uint32_t*>(d_out), w, h, nquads);
+        return hipGetLastError();
+    }
+    if (!plain && filter == 2 && k >= 3 && k <= kImgMaxFastK && out4) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(d_out);
+        switch (k / 2) {
+        case 1: return launch_gauss_tile_image<1>(stream, in, o, w, h, nframes, d_table);
+        case 2: return launch_gauss_tile_image<2>(stream, in, o, w, h, nframes, d_table);
+        case 3: return launch_gauss_tile_image<3>(stream, in, o, w, h, nframes, d_table);
+        case 4: return launch_gauss_tile_image<4>(stream, in, o, w, h, nframes, d_table);
+        case 5: return launch_gauss_tile_image<5>(stream, in, o, w, h, nframes, d_table);
+        case 6: return launch_gauss_tile_image<6>(stream, in, o, w, h, nframes, d_table);
+        case 7: return launch_gauss_tile_image<7>(stream, in, o, w, h, nframes, d_table);
+        case 8: return launch_gauss_tile_image<8>(stream, in, o, w, h, nframes, d_table);
+        case 9: return launch_gauss_tile_image<9>(stream, in, o, w, h, nframes, d_table);
+        case 10: return launch_gauss_tile_image<10>(stream, in, o, w, h, nframes, d_table);
+        case 11: return launch_gauss_tile_image<11>(stream, in, o, w, h, nframes, d_table);
+        case 12: return launch_gauss_tile_image<12>(stream, in, o, w, h, nframes, d_table);
+        default: break;
+        }
+    }
     if (filter == 0) {
         hipLaunchKernelGGL(image2d_gray_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, in, d_out, npx);
     } else if (filter == 2) {

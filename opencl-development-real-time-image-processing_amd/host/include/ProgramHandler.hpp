@@ -49,6 +49,18 @@ public:
                                              double& avg_opencl_kernel_read_time, double& avg_opencl_kernel_operation,
                                              cl_int& width, cl_int& height, Logger& logger, std::string method);
 
+    // --- MI355X extension: a batch sharded over several GPUs -------------------------------------------------
+    // Nothing in the reference to match (one queue on one device, RT/src/ProgramHandler.cpp:108).  `rgba_frames`
+    // holds nframes equally sized RGBA frames back to back; they are cut into contiguous ranges, one per entry of
+    // `devices` (HIP ordinals; empty = every visible GPU; an ordinal may repeat), and every GPU streams its range
+    // on its own host thread and stream (mi355_group_filter_batched).  method: as PerformOpenCL, plus "PIPELINE"
+    // (gray -> Gaussian -> Sobel fused).  Output: the frames' results back to back, in input order.  Errors end
+    // the process the way Controller::CheckError does.
+    std::vector<unsigned char> PerformOpenCLBatch(const std::vector<unsigned char>& rgba_frames, int nframes,
+                                                  cl_int width, cl_int height, Logger& logger, std::string method,
+                                                  std::vector<int> devices = {});
+    ~ProgramHandler();
+
 private:
     struct Options {
         int iterations = 1;
@@ -61,6 +73,9 @@ private:
     Options m_opt;
     std::vector<std::string> m_methods;                              // the three family names, in the reference's order
     std::map<std::string, std::vector<std::string>> m_kernel_files;  // family -> {image kernel, buffer kernel}
+
+    struct mi355_group* m_group = nullptr;                           // PerformOpenCLBatch: created on first use
+    std::vector<int> m_group_devices;
 
     void LoadFrame(std::string image_path, std::vector<unsigned char>* input_data, cl_int* width, cl_int* height,
                    Logger& logger);

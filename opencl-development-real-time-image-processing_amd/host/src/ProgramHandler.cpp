@@ -11,6 +11,9 @@
 #include <chrono>
 #include <cstdlib>
 #include <fstream>
+#include <iostream>
+
+#include "../../../include/mi355_imgfilter.h"
 
 ProgramHandler::ProgramHandler(int number_of_iterations, bool log_events, bool display_images,
                                bool display_terminal_results, bool bypass_image_support, int gaussian_kernel_size,
@@ -286,4 +289,53 @@ std::vector<unsigned char> ProgramHandler::PerformOpenCL(Controller& controller,
     const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     logger.log("OpenCL " + method + " execution time: " + std::to_string(ms) + " ms", Logger::LogLevel::INFO);
     return function_output;
+}
+
+// ---- MI355X extension: one batch over several GPUs (include/mi355_imgfilter.h "device group") ---------------------
+ProgramHandler::~ProgramHandler()
+{
+    if (m_group)
+        mi355_group_destroy(m_group);
+}
+
+std::vector<unsigned char> ProgramHandler::PerformOpenCLBatch(const std::vector<unsigned char>& rgba_frames, int nframes,
+                                                              cl_int width, cl_int height, Logger& logger,
+                                                              std::string method, std::vector<int> devices)
+{
+    auto fail = [&](const std::string& what, int rc) {
+        logger.log("ERROR: " + what + " (" + std::string(mi355_strerror(rc)) + ")", Logger::LogLevel::ERROR);
+        std::cerr << "ERROR: " << what << " (" << mi355_strerror(rc) << ")" << std::endl;
+        exit(EXIT_FAILURE);
+    };
+    if (devices.empty()) {
+        int n = 0;
+        mi355_device_count(&n);
+        for (int i = 0; i < n; i++)
+            devices.push_back(i);
+    }
+    if (nframes <= 0 || width <= 0 || height <= 0 ||
+        rgba_frames.size() < (size_t)nframes * (size_t)width * (size_t)height * 4)
+        fail("PerformOpenCLBatch: frame buffer smaller than nframes x width x height x 4", MI355_ERR_BAD_ARG);
+    if (!m_group || devices != m_group_devices) {
+        if (m_group)
+            mi355_group_destroy(m_group);
+        m_group = nullptr;
+        const int rc = mi355_group_create((int)devices.size(), devices.data(), &m_group);
+        if (rc != MI355_OK)
+            fail("PerformOpenCLBatch: no usable GPU group", rc);
+        m_group_devices = devices;
+    }
+    const int filter = method == "PIPELINE" ? MI355_FILTER_PIPELINE
+                                            : (method_index(method) == 1 ? MI355_FILTER_SOBEL
+                                               : method_index(method) == 2 ? MI355_FILTER_GAUSS : MI355_FILTER_GRAY);
+    std::vector<unsigned char> out((size_t)nframes * width * height * (size_t)mi355_filter_out_bpp(filter));
+    double ms = 0.0;
+    logger.log("Performing " + method + " on " + std::to_string(nframes) + " frames over " +
+                   std::to_string(devices.size()) + " GPU(s)...", Logger::LogLevel::INFO);
+    const int rc = mi355_group_filter_batched(m_group, filter, rgba_frames.data(), out.data(), width, height, nframes,
+                                              m_opt.gauss_k, m_opt.gauss_sigma, &ms);
+    if (rc != MI355_OK)
+        fail("PerformOpenCLBatch: " + method + " failed", rc);
+    logger.log(method + " batch execution time: " + std::to_string(ms) + " ms", Logger::LogLevel::INFO);
+    return out;
 }

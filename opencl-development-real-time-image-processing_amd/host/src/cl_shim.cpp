@@ -2,6 +2,7 @@
 // (RT/RealtimeImageProcessing.cpp:282-285,423-426; RT/src/ProgramHandler.cpp:62,85;
 // RT/src/InfoPlatform.cpp:65,75), implemented over the records in handles.hpp.  No OpenCL runtime.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "handles.hpp"
@@ -78,14 +79,21 @@ HOST_API cl_int clGetDeviceInfo(cl_device_id device, cl_device_info name, size_t
         return mi355_host::put_string(buf, size, value, size_ret);
     }
     if (name == CL_DEVICE_IMAGE_SUPPORT) {
-        // The image2d_t semantics exist (csrc/image2d.hip, mi355_image2d_rgba8): an application that does NOT bypass
-        // image support (no shipped one: RT/RealtimeImageProcessing.cpp:23) gets them, as on an image-capable device.
+        // CL_FALSE: an application that does not bypass image support (no shipped one does,
+        // RT/RealtimeImageProcessing.cpp:23) then takes its own "device does not support images" branch
+        // (RT/src/ProgramHandler.cpp:78-84) and stays on the buffer kernels — the 0.64-0.75-of-roofline path with the
+        // CPU path's pixel values.  The image2d_t semantics exist (csrc/image2d.hip, mi355_image2d_rgba8) but they
+        // compute DIFFERENT pixels (zero borders, image-mode table, red-channel Sobel) at a lower rate
+        // (INTEGRATION.md "image2d_t mode"), so they are an explicit opt-in: MI355_CL_IMAGE_SUPPORT=1 in the
+        // environment of the host process, or Controller::SetImageSupport(CL_TRUE) after InitOpenCL.  This shim
+        // exports no clCreateImage2D / clEnqueue{Read,Write}Image: only the Controller-level image path is backed.
         if (size_ret)
             *size_ret = sizeof(cl_bool);
         if (value) {
             if (size < sizeof(cl_bool))
                 return CL_INVALID_VALUE;
-            *static_cast<cl_bool*>(value) = CL_TRUE;
+            const char* e = std::getenv("MI355_CL_IMAGE_SUPPORT");
+            *static_cast<cl_bool*>(value) = (e && e[0] == '1') ? CL_TRUE : CL_FALSE;
         }
         return CL_SUCCESS;
     }

@@ -6,12 +6,14 @@
 //   host_app <in.rgba> <width> <height> <out_prefix> [<image.ppm>]
 // writes <out_prefix>.gray (w*h*4), .edge (w*h), .gauss (w*h*4), .gauss17 (w*h*4, the ProgramHandler
 // default k=17 sigma=6), .weights (25 floats), .prof (6 u64 from one Controller call) and, when a PPM is
-// given, .ppm_gray from the N-iteration PerformOpenCL(image_path, ...) overload.
+// given, .ppm_gray from the N-iteration PerformOpenCL(image_path, ...) overload; .batch_pipe (w*h) = first frame of a
+// five-frame PerformOpenCLBatch("PIPELINE") over a two-member group.
 #include <ProgramHandler.hpp>
 #include <FileHandler.hpp>
 #include <Comparator.hpp>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 
@@ -111,6 +113,25 @@ int main(int argc, char** argv)
         controller.Cleanup(context, queue, program, kernel);
     }
 
+    // MI355X extension: the same frame five times as one batch over two group members bound to GPU 0 (own thread,
+    // own stream each) — every frame's result must be the per-frame call's
+    {
+        std::vector<unsigned char> batch;
+        for (int f = 0; f < 5; f++)
+            batch.insert(batch.end(), rgba.begin(), rgba.end());
+        auto be = ph5.PerformOpenCLBatch(batch, 5, w, h, logger, "EDGE", {0, 0});
+        auto bg = ph5.PerformOpenCLBatch(batch, 5, w, h, logger, "GAUSSIAN", {0, 0});
+        auto bp = ph5.PerformOpenCLBatch(batch, 5, w, h, logger, "PIPELINE", {0, 0});
+        if (be.size() != edge.size() * 5 || bg.size() != gauss.size() * 5 || bp.size() != edge.size() * 5)
+            return 6;
+        for (int f = 0; f < 5; f++) {
+            if (!std::equal(edge.begin(), edge.end(), be.begin() + (long)f * (long)edge.size()) ||
+                !std::equal(gauss.begin(), gauss.end(), bg.begin() + (long)f * (long)gauss.size()))
+                return 7;
+        }
+        dump(prefix + ".batch_pipe", bp.data(), edge.size());
+    }
+
     if (argc > 5) {
         cl_context context;
         cl_command_queue queue;
@@ -141,6 +162,15 @@ int main(int argc, char** argv)
         phi.AddKernels(GAUSSIAN_KERNELS, "GAUSSIAN");
         Controller image_controller;
         auto igray = run(phi, image_controller, logger, frame, w, h, "GRAYSCALE");
+        // the device reports CL_DEVICE_IMAGE_SUPPORT = CL_FALSE unless the host process opted in
+        // (MI355_CL_IMAGE_SUPPORT=1): without the opt-in a BYPASS = false application stays on the buffer path
+        const char* optin = std::getenv("MI355_CL_IMAGE_SUPPORT");
+        if (!(optin && optin[0] == '1')) {
+            if (image_controller.GetImageSupport() != CL_FALSE || igray != gray)
+                return 8;
+            std::printf("host_app ok (image support not opted in)\n");
+            return 0;
+        }
         if (image_controller.GetImageSupport() != CL_TRUE)
             return 6;
         auto iedge = run(phi, image_controller, logger, frame, w, h, "EDGE");

@@ -114,6 +114,20 @@ def load_library(path=None):
         "mi355_dev_free": [_vp, _vp],
         "mi355_copy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
         "mi355_copy_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
+        "mi355_group_create": [_ci, ctypes.POINTER(_ci), ctypes.POINTER(_vp)],
+        "mi355_group_destroy": [_vp],
+        "mi355_group_size": [_vp, ctypes.POINTER(_ci)],
+        "mi355_group_member_ctx": [_vp, _ci, ctypes.POINTER(_vp)],
+        "mi355_group_member_status": [_vp, _ci],
+        "mi355_group_shard": [_ci, _ci, _ci, ctypes.POINTER(_ci), ctypes.POINTER(_ci)],
+        "mi355_group_set_gauss_mode": [_vp, _ci],
+        "mi355_group_set_impl": [_vp, _ci],
+        "mi355_group_set_input_format": [_vp, _ci],
+        "mi355_group_set_gauss_weights": [_vp, _ci, ctypes.c_float, _f32p],
+        "mi355_group_filter_batched": [_vp, _ci, _u8p, _u8p, _ci, _ci, _ci, _ci, ctypes.c_float,
+                                       ctypes.POINTER(ctypes.c_double)],
+        "mi355_group_filter_dev": [_vp, _ci, ctypes.POINTER(_vp), ctypes.POINTER(_vp), _ci, _ci, ctypes.POINTER(_ci), _ci,
+                                   ctypes.c_float],
         "mi355_timer_begin": [_vp],
         "mi355_timer_end": [_vp, _f32p],
     }
@@ -386,3 +400,90 @@ class Context:
         ms = ctypes.c_float(0)
         _check("mi355_timer_end", self._lib.mi355_timer_end(self._h, ctypes.byref(ms)), self._h)
         return ms.value
+
+
+def group_shard(member, nmembers, nframes):
+    """(first_frame, count) of one member: mi355_group_shard, a pure host function (= bench.shard_range's strong split)."""
+    a, b = _ci(0), _ci(0)
+    _check("mi355_group_shard", load_library().mi355_group_shard(int(member), int(nmembers), int(nframes),
+                                                                  ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
+
+
+class Group:
+    """mi355_group_*: one batch of frames sharded over several GPUs, one context + one host thread per member.
+    `devices`: HIP ordinals, one per member (an ordinal may repeat: members then share that GPU)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._h = _vp()
+        devs = (_ci * len(devices))(*[int(d) for d in devices])
+        _check("mi355_group_create", self._lib.mi355_group_create(len(devices), devs, ctypes.byref(self._h)))
+        self.size = len(devices)
+
+    def close(self):
+        if self._h:
+            self._lib.mi355_group_destroy(self._h)
+            self._h = _vp()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def member(self, i):
+        """A borrowed Context of member i (device memory, copies, checksums); do not close it."""
+        h = _vp()
+        _check("mi355_group_member_ctx", self._lib.mi355_group_member_ctx(self._h, int(i), ctypes.byref(h)))
+        c = Context.__new__(Context)
+        c._lib, c._h = self._lib, h
+        c.close = lambda: None
+        return c
+
+    def member_status(self, i):
+        return self._lib.mi355_group_member_status(self._h, int(i))
+
+    def set_gauss_mode(self, mode):
+        _check("mi355_group_set_gauss_mode", self._lib.mi355_group_set_gauss_mode(self._h, int(mode)))
+
+    def set_impl(self, impl):
+        _check("mi355_group_set_impl", self._lib.mi355_group_set_impl(self._h, int(impl)))
+
+    def set_input_format(self, fmt):
+        _check("mi355_group_set_input_format", self._lib.mi355_group_set_input_format(self._h, int(fmt)))
+        self._in_ch = 3 if fmt == INPUT_BGR else 4
+
+    def set_gauss_weights(self, k, sigma, table):
+        table = np.ascontiguousarray(table, np.float32)
+        rc = self._lib.mi355_group_set_gauss_weights(self._h, int(k), float(sigma), table.ctypes.data_as(_f32p))
+        _check("mi355_group_set_gauss_weights", rc)
+
+    def filter_batched(self, filt, frames, k=0, sigma=0.0, out=None):
+        """Host frames (n, h, w, c) -> (out, elapsed_ms): every member streams its contiguous range."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        n, h, w, c = frames.shape
+        assert c == getattr(self, "_in_ch", 4)
+        bpp = OUT_BPP[filt]
+        if out is None:
+            out = np.empty((n, h, w, 4) if bpp == 4 else (n, h, w), np.uint8)
+        ms = ctypes.c_double(0)
+        rc = self._lib.mi355_group_filter_batched(self._h, int(filt), frames.ctypes.data_as(_u8p), out.ctypes.data_as(_u8p),
+                                                  w, h, n, int(k), float(sigma), ctypes.byref(ms))
+        _check("mi355_group_filter_batched", rc)
+        return out, ms.value
+
+    def filter_dev(self, filt, d_in, d_out, w, h, nframes, k=0, sigma=0.0):
+        """Device-resident: d_in[m] / d_out[m] / nframes[m] per member; launches everywhere, returns when all are done."""
+        m = self.size
+        a = (_vp * m)(*[_vp(int(x or 0)) for x in d_in])
+        b = (_vp * m)(*[_vp(int(x or 0)) for x in d_out])
+        nf = (_ci * m)(*[int(x) for x in nframes])
+        rc = self._lib.mi355_group_filter_dev(self._h, int(filt), a, b, int(w), int(h), nf, int(k), float(sigma))
+        _check("mi355_group_filter_dev", rc)

@@ -66,6 +66,33 @@ def test_argument_validation_needs_no_gpu(pkg):
     assert lib.mi355_device_count(ctypes.byref(n)) == 0 and n.value >= 0
 
 
+def test_group_shard_is_bench_shard_range_and_group_validation(pkg):
+    """mi355_group_shard (pure host function of the product library) makes the split bench.py's shard_range makes over
+    ranks; group creation without a GPU fails with an error code, nothing crashes."""
+    import bench
+    for n in (1, 2, 3, 4, 8):
+        for total in (0, 1, 7, 8, 9, 512):
+            spans = [pkg.group_shard(m, n, total) for m in range(n)]
+            assert sum(c for _, c in spans) == total and spans[0][0] == 0
+            if total:
+                assert spans == [bench.shard_range(m, n, 256, total) for m in range(n)]
+    assert pkg.group_shard(3, 8, 512) == (192, 64)      # BASELINE config 5
+    lib = pkg.load_library()
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.mi355_group_shard(2, 2, 8, ctypes.byref(a), ctypes.byref(b)) == -1
+    assert lib.mi355_group_shard(0, 0, 8, ctypes.byref(a), ctypes.byref(b)) == -1
+    assert lib.mi355_group_shard(0, 2, 8, None, ctypes.byref(b)) == -1
+    g = ctypes.c_void_p()
+    assert lib.mi355_group_create(0, None, ctypes.byref(g)) == -1
+    assert lib.mi355_group_create(2, None, None) == -1
+    assert lib.mi355_group_destroy(None) == -1
+    assert lib.mi355_group_filter_batched(None, 0, None, None, 4, 4, 1, 0, 0.0, None) == -1
+    n = ctypes.c_int(0)
+    lib.mi355_device_count(ctypes.byref(n))
+    if n.value == 0:
+        assert lib.mi355_group_create(2, None, ctypes.byref(g)) == -3 and not g.value   # MI355_ERR_NO_DEVICE
+
+
 def test_no_product_file_references_the_oracle():
     """The product path must not import, link or execute anything under oracle/."""
     import os

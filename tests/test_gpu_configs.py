@@ -230,6 +230,84 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert strong["config"]["total_frames"] == 12 and strong["checksum"] == one_p["checksum"]
 
 
+# ---- mi355_group_*: the product-level sharded batch (SURVEY.md §8b "Threading", §8e) -------------------------------
+@pytest.mark.parametrize("members", [1, 2, 3])
+def test_group_shards_a_host_batch_over_its_members(pkg, oracle, members):
+    """mi355_group_filter_batched with 1, 2 and 3 members bound to this box's one GPU (own context, own stream, own
+    host thread each): contiguous frame ranges, every filter equal to the oracle frame by frame (FAST Gaussian within
+    1 LSB) and equal, byte for byte, to what one context computes for the whole batch."""
+    n, h, w = 7, 120, 256
+    frames = oracle.synth_rgba(w, h, n, first_frame=30, mode=1)
+    frames[2, ..., 3] = 128                                           # one frame with another (constant) alpha
+    with pkg.Group([0] * members) as g, pkg.Context(0) as one:
+        assert g.size == members
+        for filt, k, sigma, ref in (
+                (pkg.FILTER_GRAY, 0, 0.0, lambda f: oracle.gray_rgba(f)),
+                (pkg.FILTER_SOBEL, 0, 0.0, lambda f: oracle.sobel_rgba(f)),
+                (pkg.FILTER_PIPELINE, 5, 1.5, lambda f: oracle.pipeline_rgba(f, 5, 1.5)),
+                (pkg.FILTER_GAUSS, 5, 1.5, lambda f: oracle.gauss_rgba(f, 5, 1.5)),
+                (pkg.FILTER_GAUSS, 17, 6.0, lambda f: oracle.gauss_rgba(f, 17, 6.0))):
+            got, ms = g.filter_batched(filt, frames, k, sigma)
+            assert ms > 0 and all(g.member_status(m) == 0 for m in range(members))
+            whole = one._host(filt, frames, k, sigma)
+            if k != 17:   # (k = 17: AUTO picks the matrix-core or the VALU kernel by launch size — both within 1 LSB of
+                assert np.array_equal(got, whole), (filt, k)   # the CPU path, not bit-identical to each other)
+            for f in range(n):
+                d = _absdiff(got[f], ref(frames[f]).reshape(got[f].shape))
+                assert d.max() <= (1 if filt == pkg.FILTER_GAUSS else 0), (filt, k, f)
+        # EXACT mode and an installed table reach every member
+        g.set_gauss_mode(pkg.GAUSS_EXACT)
+        got, _ = g.filter_batched(pkg.FILTER_GAUSS, frames, 5, 1.5)
+        assert all(np.array_equal(got[f], oracle.gauss_rgba(frames[f], 5, 1.5)) for f in range(n))
+        g.set_gauss_mode(pkg.GAUSS_FAST)
+        box = np.full((3, 3), 1.0 / 9, np.float32)
+        g.set_gauss_weights(3, 4.0, box)
+        got, _ = g.filter_batched(pkg.FILTER_GAUSS, frames, 3, 4.0)
+        assert all(_absdiff(got[f], oracle.gauss_rgba(frames[f], 3, weights=box)).max() <= 1 for f in range(n))
+        # fewer frames than members: the idle members report OK
+        got, _ = g.filter_batched(pkg.FILTER_SOBEL, frames[:1])
+        assert np.array_equal(got[0], oracle.sobel_rgba(frames[0]))
+        # a bad request comes back as the failing member's code, nothing hangs
+        with pytest.raises(pkg.Mi355Error):
+            g.filter_batched(pkg.FILTER_GAUSS, frames, 4, 1.5)
+
+
+def test_group_device_resident_call_adds_up_to_the_single_context_checksum(pkg, oracle):
+    """mi355_group_filter_dev: every member owns its shard in device memory (bench.py's layout, inside one process);
+    the per-member checksums, keyed by the global word index, add up to the checksum of one context's whole batch."""
+    import bench
+    n, w, h, members = 10, 640, 360, 2
+    with pkg.Group([0, 0]) as g, pkg.Context(0) as one:
+        d_all = one.alloc(n * w * h * 4)
+        d_all_out = one.alloc(n * w * h)
+        one.synth_dev(d_all, w, h, n, first_frame=0, seed=0x5EED, mode=0)
+        one.filter_dev(pkg.FILTER_PIPELINE, d_all, d_all_out, w, h, n, 5, 1.5)
+        whole = one.checksum_dev(d_all_out, n * w * h)
+        d_in, d_out, counts, total = [], [], [], 0
+        for m in range(members):
+            first, cnt = pkg.group_shard(m, members, n)
+            c = g.member(m)
+            d_in.append(c.alloc(cnt * w * h * 4))
+            d_out.append(c.alloc(cnt * w * h))
+            c.synth_dev(d_in[-1], w, h, cnt, first_frame=first, seed=0x5EED, mode=0)
+            c.sync()
+            counts.append(cnt)
+        g.filter_dev(pkg.FILTER_PIPELINE, d_in, d_out, w, h, counts, 5, 1.5)
+        for m in range(members):
+            first, cnt = pkg.group_shard(m, members, n)
+            total += g.member(m).checksum_dev(d_out[m], cnt * w * h, index_base=bench.checksum_index_base(first, w, h, 1))
+        assert total % (1 << 64) == whole
+        f0 = np.empty((h, w), np.uint8)
+        g.member(1).d2h(f0, d_out[1])
+        first1, _ = pkg.group_shard(1, members, n)
+        assert np.array_equal(f0, oracle.pipeline_rgba(oracle.synth_rgba(w, h, 1, first_frame=first1)[0], 5, 1.5))
+        for m in range(members):
+            g.member(m).free(d_in[m])
+            g.member(m).free(d_out[m])
+        one.free(d_all)
+        one.free(d_all_out)
+
+
 def test_bench_rccl_branch_with_one_rank():
     """bench.py's RCCL branch, for real, on this box's one GPU: `--force-dist` with a torchrun-style environment
     (set here, before the child starts: no re-exec of a GPU process) makes init_process_group("nccl", device_id=...),
@@ -473,6 +551,21 @@ def test_image2d_mode_semantics(ctx, pkg, oracle, h, w):
         ctx.image2d(pkg.FILTER_PIPELINE, img)
     with pytest.raises(pkg.Mi355Error):
         ctx.image2d(pkg.FILTER_GAUSS, img, 4, 1.0)
+
+
+@pytest.mark.parametrize("h,w,k,sigma", [(360, 640, 17, 6.0), (819, 1023, 5, 1.5), (70, 200, 25, 8.0), (40, 130, 27, 8.0),
+                                         (33, 64, 9, 2.5), (16, 4, 7, 2.0)])
+def test_image2d_mode_tiled_kernels_on_larger_frames(ctx, pkg, oracle, h, w, k, sigma):
+    """The LDS-tiled image-mode Gaussian (k <= 25; k = 27 takes the per-pixel fallback), the 16 B/lane grayscale and the
+    4-outputs-per-lane Sobel on frames of many tiles, ragged widths included (1023 x 819 is the reference's largest
+    image, k = 17 sigma = 6 its application default): the same bytes as the restated OpenCL-C semantics."""
+    img = rand_rgba(h, w, seed=h + 7 * w + k, alpha=None)
+    got, _ = ctx.image2d(pkg.FILTER_GAUSS, img, k, sigma)
+    assert np.array_equal(got, oracle.image2d_gauss(img, k, sigma))
+    got, _ = ctx.image2d(pkg.FILTER_GRAY, img)
+    assert np.array_equal(got, oracle.image2d_gray(img))
+    got, _ = ctx.image2d(pkg.FILTER_SOBEL, img)
+    assert np.array_equal(got, oracle.image2d_sobel(img))
 
 
 def test_image2d_mode_fixture(ctx, pkg, oracle, fixture_rgba):

@@ -70,10 +70,19 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
     ppm.write_bytes(b"P6\n# fixture crop\n128 96\n255\n" + crop.tobytes())
     prefix = str(tmp_path / "out")
     # the reference's ProgramHandler opens RealtimeImageProcessing.log in the working directory (ProgramHandler.cpp:14)
+    # default: CL_DEVICE_IMAGE_SUPPORT = CL_FALSE — a BYPASS_IMAGE_SUPPORT = false application stays on the
+    # buffer kernels (host_app checks that its grayscale equals the buffer-mode one and stops there)
+    env = {k: v for k, v in os.environ.items() if k != "MI355_CL_IMAGE_SUPPORT"}
     run = subprocess.run([HOST_APP, str(raw), str(w), str(h), prefix, str(ppm)], capture_output=True, text=True,
-                         timeout=300, cwd=str(tmp_path))
+                         timeout=300, cwd=str(tmp_path), env=env)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
-    assert "host_app ok" in run.stdout
+    assert "host_app ok (image support not opted in)" in run.stdout
+    assert "Device does not support images. Using buffers instead of image2D structures." in run.stdout
+    # the explicit opt-in: the whole run again, image2d_t semantics for the BYPASS = false ProgramHandler
+    run = subprocess.run([HOST_APP, str(raw), str(w), str(h), prefix, str(ppm)], capture_output=True, text=True,
+                         timeout=300, cwd=str(tmp_path), env=dict(env, MI355_CL_IMAGE_SUPPORT="1"))
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-2000:]
+    assert "host_app ok\n" in run.stdout and "Device supports images." in run.stdout
     # the reference's bootstrap chatter is preserved (Controller.cpp:25,35,62,111,127,177,189)
     for line in ("Number of platforms: 1", "Successfully created a context", "Successfully created CommandQueue",
                  "Successfully created a program", "Successfully created the gaussian_blur kernel",
@@ -95,6 +104,9 @@ def test_host_app_matches_oracle(host_built, oracle, tmp_path, fixture_rgb):
     assert prof.size == 12 and (np.diff(prof[:6].astype(np.int64)) >= 0).all() and prof[6] >= prof[5]
     rgba = np.dstack([crop, np.full(crop.shape[:2], 255, np.uint8)])
     assert np.array_equal(load(".ppm_gray", (96, 128, 4)), oracle.gray_rgba(rgba))
+    # ProgramHandler::PerformOpenCLBatch (MI355X extension): five frames over a two-member group; host_app itself
+    # checked EDGE / GAUSSIAN against the per-frame calls, the fused pipeline is checked here against the chained oracle
+    assert np.array_equal(load(".batch_pipe", (h, w)), oracle.pipeline_rgba(frame, 5, 1.5))
     # BYPASS_IMAGE_SUPPORT = false: image2d_t semantics and output shapes ("w*h gray bytes then zeros")
     ig = load(".img_gray", (h * w * 4,))
     assert np.array_equal(ig[: h * w].reshape(h, w), oracle.image2d_gray(frame)) and not ig[h * w:].any()
