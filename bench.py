@@ -151,6 +151,31 @@ def gather_per_rank(dist, rank, world, record, device):
     return out
 
 
+def kernel_source_hash(kernel_symbol):
+    """sha256 (16 hex digits) over the csrc file that defines the kernel `kernel_symbol` names plus the headers every
+    kernel shares.  profiles/pmc_traffic.json stores it beside each offline HBM-traffic figure (tools/prof_summary.py),
+    and the figure is only reported while the hash still matches: a kernel change cannot leave a stale `traffic`."""
+    import hashlib
+    import re
+    csrc = os.path.join(entry.PKG_DIR, "csrc")
+    m = re.search(r"(\w+_kernel)\b", kernel_symbol or "")
+    if not m:
+        return None
+    name = m.group(1)
+    owner = None
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith(".hip") and re.search(r"\b%s\s*\(" % re.escape(name), open(os.path.join(csrc, fn)).read()):
+            owner = fn
+            break
+    if owner is None:
+        return None
+    hsh = hashlib.sha256()
+    for fn in [owner] + sorted(f for f in os.listdir(csrc) if f.endswith(".hpp")):
+        hsh.update(fn.encode())
+        hsh.update(open(os.path.join(csrc, fn), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def checksum_index_base(first_frame, w, h, out_bpp):
     """Word index of this rank's first output word in the whole job's output (checksums add up over ranks)."""
     return first_frame * (w * h * out_bpp // 4)
@@ -417,9 +442,15 @@ def main(argv=None):
                 pmc = json.load(open(pmc_path))
                 key = "%s_%dx%d_f%d_k%d" % (args.filter, w, h, F, args.k)
                 if key in pmc:
-                    traffic = pmc[key]["hbm_bytes_per_launch"]
-                    traffic_src = ("OFFLINE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-                                   "(tools/prof.sh), committed in profiles/pmc_traffic.json[%s]; not measured in this run" % key)
+                    want = kernel_source_hash(pmc[key].get("kernel"))
+                    if want is not None and pmc[key].get("source_sha") == want:
+                        traffic = pmc[key]["hbm_bytes_per_launch"]
+                        traffic_src = ("OFFLINE: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                                       "(tools/prof.sh), committed in profiles/pmc_traffic.json[%s] for kernel source %s; "
+                                       "not measured in this run" % (key, want))
+                    else:
+                        traffic_src = ("none: profiles/pmc_traffic.json[%s] was measured on another version of the kernel's "
+                                       "source (%s, now %s): re-run tools/prof.sh" % (key, pmc[key].get("source_sha"), want))
             except Exception:
                 traffic = None
         strong = bool(args.total_frames)

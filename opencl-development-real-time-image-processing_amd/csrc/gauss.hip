@@ -40,7 +40,9 @@ GaussKernel choose(const uint8_t* d_in, const uint8_t* d_out, int w, int h, int 
         return GaussKernel::Exact;
     if (exact || impl == MI355_IMPL_TILE)
         return GaussKernel::Tile;
-    const bool mfma_ok = gauss_mfma_supported(d_in, d_out, w, h, coef);
+    // (frames of 2 GiB and more — 23,000 x 23,000 pixels — stay on the VALU kernels: the LDS-staged matrix-core kernel
+    // that used to take them is an A/B partner in the tuning build only)
+    const bool mfma_ok = gauss_mfma_reg_supported(d_in, d_out, w, h, coef);
     if (impl == MI355_IMPL_MFMA && mfma_ok)
         return GaussKernel::Mfma;
     // a launch must be worth a 64-pixel-wide, 16-row-blocked decomposition
@@ -70,17 +72,16 @@ hipError_t launch_gauss(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out,
 {
     switch (choose(d_in, d_out, w, h, nframes, coef, exact, impl)) {
     case GaussKernel::Mfma:
-        // the register-operand skeleton (gauss_mfma_reg.hip) is the faster one; the LDS-staged kernel stays as its
-        // A/B partner (tuning build: MI355_MFMA_LDS=1) and for frames of 2 GiB and more
-        if (!tune_env("MI355_MFMA_LDS") && gauss_mfma_reg_supported(d_in, d_out, w, h, coef)) {
-            // gauss_mfma_dma.hip = the same kernel with its input tiles staged by LDS-DMA: same bits, same speed
-            // (-1 .. +2 % over five launch shapes, profiles/r02_mfma_ablations.txt), so the simpler one stays the default
-            // and the DMA kernel its A/B partner (tuning build: MI355_MFMA_DMA=1)
-            if (tune_env("MI355_MFMA_DMA"))
-                return launch_gauss_mfma_dma(stream, d_in, d_out, w, h, nframes, coef);
-            return launch_gauss_mfma_reg(stream, d_in, d_out, w, h, nframes, coef);
-        }
-        return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
+#ifdef MI355_TUNE_ENV
+        // A/B partners, tuning build only (csrc/Makefile TSRCS): the LDS-staged first version (MI355_MFMA_LDS=1) and the
+        // LDS-DMA input staging (MI355_MFMA_DMA=1) — same bits as gauss_mfma_reg.hip, not faster (-1 .. +2 % over five
+        // launch shapes, profiles/r02_mfma_ablations.txt)
+        if (tune_env("MI355_MFMA_LDS") && gauss_mfma_supported(d_in, d_out, w, h, coef))
+            return launch_gauss_mfma(stream, d_in, d_out, w, h, nframes, coef);
+        if (tune_env("MI355_MFMA_DMA") && gauss_mfma_dma_supported(d_in, d_out, w, h, coef))
+            return launch_gauss_mfma_dma(stream, d_in, d_out, w, h, nframes, coef);
+#endif
+        return launch_gauss_mfma_reg(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Exact: return launch_gauss_exact(stream, d_in, d_out, w, h, nframes, coef);
     case GaussKernel::Slide: return launch_gauss_slide(stream, d_in, d_out, w, h, nframes, coef, d_flags);
     case GaussKernel::Wide: return launch_gauss_wide(stream, d_in, d_out, w, h, nframes, coef, d_flags);

@@ -730,7 +730,7 @@ def test_pipeline_eight_pixels_per_lane():
     (MI355_PIPE8=1) on small shapes: one strip / several strips / idle lanes, one band / several bands walking both
     ways, image edges, k = 3 and 5, noise, smooth and flat frames — bit-identical to the chained oracle."""
     root = entry.ROOT
-    tune_lib = os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so")
+    tune_lib = os.path.join(entry.ROOT, "tools", "lib", "libmi355_imgfilter_tune.so")
     assert os.path.exists(tune_lib), "run __graft_entry__.build()"
     env = dict(os.environ, MI355_IMGFILTER_LIB=tune_lib, MI355_PIPE8="1")
     out = subprocess.run([sys.executable, "-c", _PIPE8_SCRIPT, root], env=env, capture_output=True, text=True, timeout=600)

@@ -109,7 +109,7 @@ def test_lds_staged_partner_and_band_heights():
     import sys
     import __graft_entry__ as entry
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tune_lib = os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so")
+    tune_lib = os.path.join(entry.ROOT, "tools", "lib", "libmi355_imgfilter_tune.so")
     assert os.path.exists(tune_lib), "run __graft_entry__.build()"
     # MI355_MFMA_DMA=1: gauss_mfma_dma.hip, the register kernel with its input tiles staged by LDS-DMA (global_load_lds_dwordx4)
     for knobs in ({"MI355_MFMA_LDS": "1"}, {"MI355_MFMA_BPB": "1"}, {"MI355_MFMA_BPB": "3"}, {"MI355_MFMA_DMA": "1"},

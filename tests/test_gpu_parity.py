@@ -670,7 +670,7 @@ def test_results_do_not_depend_on_the_band_plan():
     import sys
     import __graft_entry__ as entry
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    tune_lib = os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so")
+    tune_lib = os.path.join(entry.ROOT, "tools", "lib", "libmi355_imgfilter_tune.so")
     assert os.path.exists(tune_lib), "run __graft_entry__.build()"
     digests = {}
     for plan in ({}, {"MI355_TUNE_BAND_ROWS": "1"}, {"MI355_TUNE_BAND_ROWS": "7"},

@@ -72,7 +72,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     stream = torch.cuda.current_stream(dev)
-    libdir = os.path.join(entry.PKG_DIR, "lib")
+    libdir = os.path.join(entry.ROOT, "tools", "lib")
     builds = []
     import shutil
     import tempfile

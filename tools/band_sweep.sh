@@ -1,6 +1,6 @@
 #!/bin/bash
 # the MI355_TUNE_* overrides are only compiled into the tune build (csrc/Makefile, `make tune`)
-export MI355_IMGFILTER_LIB=${MI355_IMGFILTER_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/opencl-development-real-time-image-processing_amd/lib/libmi355_imgfilter_tune.so}
+export MI355_IMGFILTER_LIB=${MI355_IMGFILTER_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/tools/lib/libmi355_imgfilter_tune.so}
 # tools/band_sweep.sh "<bench args>" v1 v2 ... : two alternating rounds of MI355_TUNE_BAND_ROWS values (tail phase off)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 ARGS=$1; shift

@@ -22,7 +22,7 @@ def main():
     lib = None
     if plain:
         os.environ["MI355_IMAGE2D_PLAIN"] = "1"
-        lib = pkg.imgfilter.load_library(os.path.join(entry.PKG_DIR, "lib", "libmi355_imgfilter_tune.so"))
+        lib = pkg.imgfilter.load_library(os.path.join(entry.ROOT, "tools", "lib", "libmi355_imgfilter_tune.so"))
     ctx = pkg.Context(0, lib=lib)
     rng = np.random.default_rng(1)
     label = "per-pixel kernels (round 2)" if plain else "tiled / vector kernels"

@@ -1,4 +1,4 @@
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-export MI355_IMGFILTER_LIB=$ROOT/opencl-development-real-time-image-processing_amd/lib/libmi355_imgfilter_tune.so
+export MI355_IMGFILTER_LIB=$ROOT/tools/lib/libmi355_imgfilter_tune.so
 row() { python3 $ROOT/bench.py --no-cpu-baseline --no-ceiling --no-side-figures --pool-candidates 1 --steps 30 --warmup 5 "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('lanes=%-3s %-40s %6.0f GB/s  %5.1f %%' % ('$L', '$*', r['achieved'], 100*r['frac']))"; }
 for rep in 1 2; do for L in 60 62 56 52 48; do export MI355_TUNE_LANES_OUT=$L; row --filter pipeline; done; done

@@ -81,6 +81,10 @@ if fetch and write:
            "hbm_read_bytes_per_launch": fb, "hbm_write_bytes_per_launch": wb, "hbm_bytes_per_launch": fb + wb,
            "correction": "read = 2 x FETCH_SIZE x 1024 (gfx950 half-count of wide coalesced reads), write = WRITE_SIZE x 1024",
            "bench_args": sys.argv[2] if len(sys.argv) > 2 else ""}
+    # the version of the kernel's source these counters belong to: bench.py reports the figure only while it matches
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    rec["source_sha"] = bench.kernel_source_hash(kname)
     print("== traffic ==")
     print(json.dumps(rec, indent=1))
     json.dump(rec, open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the MI355_TUNE_* overrides are only compiled into the tune build (csrc/Makefile, `make tune`)
-export MI355_IMGFILTER_LIB=${MI355_IMGFILTER_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/opencl-development-real-time-image-processing_amd/lib/libmi355_imgfilter_tune.so}
+export MI355_IMGFILTER_LIB=${MI355_IMGFILTER_LIB:-${GRAFT_REPO_ROOT:-/root/repo}/tools/lib/libmi355_imgfilter_tune.so}
 # tools/sweep.sh — A/B of one tuning knob through bench.py on the GPU box.
 #   tools/sweep.sh <filter> <ENV_VAR> <v1> <v2> ... [-- extra bench args]
 # e.g. tools/sweep.sh gauss MI355_TUNE_BAND_ROWS 96 128 216 -- --frames 64
