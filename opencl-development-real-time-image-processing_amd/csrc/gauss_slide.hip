@@ -198,40 +198,57 @@ struct SlideLane {
     uint32_t in_off, out_off;
     int y0, nout, nin, h;
     bool left_of_image, right_of_image, edge_strip, stores;
-    // RAGGED variant (width % 4 != 0 or buffers not 16-byte aligned): in the two edge strips every lane
-    // addresses its 4 pixels one by one, clamped to the row (which is also what replicates the edge pixel)
+    // RAGGED variant (width % 4 != 0 or buffers not 16-byte aligned): in the two edge strips the lanes that overlap the
+    // row's ends address their 4 pixels one by one, clamped to the row (which is also what replicates the edge pixel).
+    // (Round 3 tried one clamped 16-byte load + a shift by v_cndmask for those lanes instead — no divergent branch, no
+    // extra load instructions: 3.5 % SLOWER at width 1023, same box, and -2 % in the pipeline; removed.)
     uint32_t px_off[4];   // byte offsets of the 4 (clamped) pixels inside a row
     int x_lane, w;        // first pixel of the lane (may be < 0 or >= w), image width
 };
 
-// Does any of the wave's 256 pixels of this row carry an alpha other than `lo >> 24`?  mn / mx = the lane's
-// smallest / largest pixel DWORD: alpha is the top byte, so they carry the lane's smallest / largest alpha.
-__device__ __forceinline__ bool alpha_row_differs(uint32_t mn, uint32_t mx, uint32_t lo)
+// "Do this lane's four pixels all carry alpha A?" as one AND chain: with nA = (A ^ 0xFF) << 24 the top byte of
+// (p ^ nA) is 0xFF exactly where the pixel's alpha is A, so the AND over the four pixels keeps 0xFF there iff all four
+// are (two v_xor_b32 + two three-input v_bitop3_b32 + a compare).  For A = 255 (NA0: nA = 0 at compile time) it is the
+// v_and_b32 + v_bitop3_b32 + compare of the round-1 test.
+template <bool NA0>
+__device__ __forceinline__ bool alpha_row_differs(const u32x4& p, uint32_t nA)
 {
-    return __builtin_amdgcn_ballot_w64((mn < lo) | (mx > (lo | 0x00FFFFFFu))) != 0;
+    uint32_t t;
+    if constexpr (NA0)
+        t = (p.x & p.y) & (p.z & p.w);
+    else
+        t = ((p.x ^ nA) & (p.y ^ nA)) & ((p.z ^ nA) & (p.w ^ nA));
+    return __builtin_amdgcn_ballot_w64(t < 0xFF000000u) != 0;
 }
 
-// Return codes of a pass over a band
-constexpr int kBandDone = 0;         // every output row stored
-constexpr int kBandAbortFirst = 1;   // NCH = 3 only: the band's FIRST input row has mixed alphas; q[0..PF-1] still hold
-                                     // the first PF rows, so the 4-channel pass starts from them without re-loading
-constexpr int kBandAbort = 2;        // NCH = 3 only: aborted further down; the rows stored so far are correct
+// Return codes of a pass over a band (3-channel passes only stop early; the rows stored so far are correct)
+constexpr int kBandDone = 0;          // every output row stored
+constexpr int kBandAbortUniform = 1;  // AMODE 1: a row whose alpha is uniform over the strip but not 255 — worth AMODE 2
+constexpr int kBandAbort = 2;         // a row with mixed alphas, or (AMODE 2) a window that spans two values: 4 channels
+
+// AMODE of a 3-channel pass: 1 = alpha 255 only — the hot loop of opaque frames, exactly round 2's instruction stream —;
+// 2 = any constant, piecewise (value tracking, table loads, window check).  The kernel tries 1, then 2 only where 1
+// stopped at a uniform row, then the 4-channel pass.  (With both in ONE loop — a wave-uniform branch per row between the
+// two tests, a run counter — the opaque path ran 0.7-1.1 % slower than round 2's on boxes where it is not memory-bound.)
 
 // One pass over the band with NCH channels computed per pixel.  NCH = 4: the general path.  NCH = 3: the
 // constant-alpha fast path — alpha is not computed; while the last K rows carry one alpha value A over all 64 lanes
-// (halo included) every output gets the constant byte alpha_tab[A] (one min3/max3 pair and one ballot per row; the
-// value changes through a scalar branch and one s_load).  A row with mixed alphas, or an output row whose window
+// (halo included) every output gets the constant byte alpha_tab[A] (alpha_row_differs: three or four instructions per
+// row; the value changes through a scalar branch and one s_load).  A row with mixed alphas, or an output row whose window
 // spans two values, ends the pass before that row has stored anything: the rows stored so far are correct, and
 // the caller redoes the band with NCH = 4.
-template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP>
+template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP, int AMODE>
 __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi,
-                                                const uint32_t* __restrict__ alpha_tab, u32x4 (&q)[2 * R + 1],
-                                                bool preloaded)
+                                                const uint32_t* __restrict__ alpha_tab)
 {
     constexpr int K = 2 * R + 1;
+    static_assert((NCH == 4) == (AMODE == 0), "AMODE 1 / 2 belong to the 3-channel pass");
     uint32_t in_off = L.in_off, out_off = L.out_off;
-    uint32_t cur_lo = 0xFF000000u;  // alpha value (<< 24) the rows seen last carry; alpha_hi = alpha_tab[cur_lo >> 24]
-    int run = 0;                    // how many consecutive rows, the current one included, carry it
+    // AMODE 2: (A ^ 0xFF) << 24 for the alpha value A the rows seen last carry — alpha_hi = alpha_tab[A] — and how many
+    // consecutive rows, the current one included, carry it.  The first row sets them (run = 0 forces the first test to
+    // take the "value changes" branch only if the row is not 255; 255 is where alpha_hi starts).
+    uint32_t cur_nA = 0u;
+    int run = 0;
     auto load_row = [&](int i) -> u32x4 {
         // rows past the band's last input re-read that last row (an L1/L2 hit, never consumed); an UP band
         // walks from its bottom-most input row to its top-most one
@@ -266,11 +283,10 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
     // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
     // only PF of the K slots are live at a time (PF x 1 KiB in flight per wave)
     constexpr int PF = (K < 3) ? K : 3;
-    if (!preloaded) {  // wave-uniform
+    u32x4 q[K];
 #pragma unroll
-        for (int u = 0; u < PF; u++)
-            q[u] = load_row(u);
-    }
+    for (int u = 0; u < PF; u++)
+        q[u] = load_row(u);
 
     // k <= 7: ring of the last K input rows, converted to float once (row i lives in slot i % K, static after
     // unrolling); the vertical sums of an output row are formed when its window is complete — in either walking
@@ -298,14 +314,20 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
                         p = u32x4{p.w, p.w, p.w, p.w};
                 }
             }
-            if constexpr (NCH == 3) {
-                const uint32_t mn = min(min(min(p.x, p.y), p.z), p.w), mx = max(max(max(p.x, p.y), p.z), p.w);
-                if (alpha_row_differs(mn, mx, cur_lo)) {  // wave-uniform, rare: the alpha value changes here
-                    const uint32_t a_new = __builtin_amdgcn_readfirstlane(mx) & 0xFF000000u;
-                    if (alpha_row_differs(mn, mx, a_new))
-                        return (i == 0 && PF < K) ? kBandAbortFirst : kBandAbort;  // (k = 3: q[0] already holds row 3)
-                    cur_lo = a_new;
-                    alpha_hi = __builtin_amdgcn_readfirstlane(alpha_tab[a_new >> 24]);
+            if constexpr (AMODE == 1) {
+                if (alpha_row_differs<true>(p, 0u)) {  // wave-uniform: the pass ends here
+                    const uint32_t a_row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)p.x) >> 24) & 0xFFu;
+                    return alpha_row_differs<false>(p, (a_row ^ 0xFFu) << 24) ? kBandAbort : kBandAbortUniform;
+                }
+            }
+            if constexpr (AMODE == 2) {
+                if (alpha_row_differs<false>(p, cur_nA)) {  // wave-uniform, rare: the alpha value changes here
+                    const uint32_t a_new = ((uint32_t)__builtin_amdgcn_readfirstlane((int)p.x) >> 24) & 0xFFu;  // (int -> int builtin)
+                    const uint32_t nA = (a_new ^ 0xFFu) << 24;
+                    if (alpha_row_differs<false>(p, nA))
+                        return kBandAbort;
+                    cur_nA = nA;
+                    alpha_hi = __builtin_amdgcn_readfirstlane(alpha_tab[a_new]);
                     run = 0;
                 }
                 run++;
@@ -339,7 +361,7 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
             // the horizontal pass and the store with a scalar branch (m and nout live in SGPRs, so EXEC
             // stays full inside, which the DPP reads of the horizontal pass require)
             if (m >= 0 && m < L.nout) {
-                if constexpr (NCH == 3) {
+                if constexpr (AMODE == 2) {
                     if (run < K)  // the window spans two alpha values: its blurred alpha is not a constant
                         return kBandAbort;
                 }
@@ -490,27 +512,35 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
     // each needs from the other) at the same moment and the second reader hits L2 (sobel_slide.hip does the
     // same; measured there: HBM reads -12 %).  Wave-uniform: two instantiations of the band code.
     const bool up = (it.band & 1) != 0;
-    u32x4 q[K];  // the prefetch ring of input rows: shared by the two passes (kBandAbortFirst)
-    auto run = [&](auto nch, bool preloaded) -> int {
-        constexpr int NCH = decltype(nch)::value;
+    auto run = [&](auto amode) -> int {
+        constexpr int AMODE = decltype(amode)::value;
+        constexpr int NCH = AMODE == 0 ? 4 : 3;
         if constexpr (R <= 3) {  // (the k = 9 form walks down only)
             if (up)
-                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true>(L, wv, alpha_hi, alpha_tab, q, preloaded);
+                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true, AMODE>(L, wv, alpha_hi, alpha_tab);
         }
-        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false>(L, wv, alpha_hi, alpha_tab, q, preloaded);
+        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false, AMODE>(L, wv, alpha_hi, alpha_tab);
+    };
+    // 3 channels while alpha is 255; where that stops at a row of another UNIFORM alpha, 3 channels with the value
+    // tracked (constant and piecewise-constant alpha); 4 channels for what is left.  Every pass starts the band over:
+    // the rows an earlier pass stored are rewritten with the same bytes.  (Handing the rows already in flight from an
+    // aborted pass to the next was tried in round 3: no gain on alpha-noise frames — the second start-up hits L1 — and
+    // 12 more VGPRs, which cost the ragged instantiation its fourth wave.)
+    auto three_channels = [&]() -> int {
+        int code = run(std::integral_constant<int, 1>{});
+        if (code == kBandAbortUniform)
+            code = run(std::integral_constant<int, 2>{});
+        return code;
     };
     if constexpr (MODE == 0) {
-        // frames whose alpha varies from pixel to pixel fail the first row's test: the 4-channel pass then starts
-        // from the rows already in flight (no second start-up per band)
-        const int code = run(std::integral_constant<int, 3>{}, false);
-        if (code != kBandDone)
-            run(std::integral_constant<int, 4>{}, code == kBandAbortFirst);
+        if (three_channels() != kBandDone)
+            run(std::integral_constant<int, 0>{});
     } else if constexpr (MODE == 3) {
-        const int code = run(std::integral_constant<int, 3>{}, false);
+        const int code = three_channels();
         if (lane == 0)
             flags[it.work] = code == kBandDone ? 0u : 1u;
     } else {
-        run(std::integral_constant<int, 4>{}, false);
+        run(std::integral_constant<int, 0>{});
     }
 }
 
