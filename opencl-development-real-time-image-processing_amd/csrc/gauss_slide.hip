@@ -159,6 +159,8 @@ __device__ __forceinline__ uint32_t pack_px(float a, float b, float c, float d)
 // code path (o = w0*s0; o = fma(w_t, s_t, o)), so results are bit-identical.
 //  * `s_nop 1` first: a VGPR written by VALU needs 2 wait states before a DPP read of it, and the
 //    hazard recogniser does not look inside an asm statement.  Inside the block no DPP source is written.
+//    (Round 3 tried opening the block with its two plain multiplies instead of the s_nop — same bits, the hazard
+//    distance kept: no change on opaque frames, 3 % SLOWER on the 4-channel pass, same box; put back.)
 //  * volatile: the block must execute with the full EXEC mask of the wave (a DPP read of a disabled lane
 //    returns 0), so it must not be sunk into the store-predicated region.
 __device__ __forceinline__ void hpass5_dpp(float v0, float v1, float v2, float v3, float w0, float w1, float w2,
@@ -303,7 +305,10 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
 #pragma unroll
         for (int u = 0; u < K; u++) {
             const int i = base + u;
-            u32x4 p = q[u];
+            // the row is used in place where its slot is not the one the next load fills (k >= 5: PF < K) — a private copy
+            // cost two v_mov_b64 per row on every strip for the sake of the edge strips' replication
+            u32x4 p_copy = q[u];
+            u32x4& p = *((PF < K) ? &q[u] : &p_copy);
             q[(u + PF) % K] = load_row(i + PF);
             if constexpr (!RAGGED) {
                 if (L.edge_strip) {
