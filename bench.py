@@ -78,6 +78,8 @@ def parse(argv=None):
     p.add_argument("--random-alpha", action="store_true", help="overwrite the frames' alpha (255 by definition "
                    "of the synthetic frames, as after cvtColor BGR2RGBA) with noise: measures the Gaussian's "
                    "general 4-channel path instead of its opaque fast path")
+    p.add_argument("--const-alpha", type=int, default=-1, help="overwrite the frames' alpha with this constant (0..255): "
+                   "the Gaussian's constant-alpha pass (3 channels + a table byte) instead of the alpha = 255 pass")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="budget for the CPU baseline leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ceiling", action="store_true", help="skip the stream-copy ceiling measurement")
@@ -327,6 +329,8 @@ def main(argv=None):
         del big
     if args.random_alpha:
         d_in[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
+    if 0 <= args.const_alpha <= 255:
+        d_in[..., 3] = args.const_alpha
 
     # coefficient table: rank 0 generates, RCCL broadcasts over xGMI, every rank installs the same bytes
     table = None
@@ -477,7 +481,8 @@ def main(argv=None):
                        "frames_per_gpu": F, "total_frames": red["pixels"] // (w * h), "width": w, "height": h,
                        "parallelism": "frames sharded x%d" % world,
                        "impl": args.impl,
-                       "alpha": "random" if args.random_alpha else "255 (opaque frames, as after cvtColor BGR2RGBA)",
+                       "alpha": "random" if args.random_alpha else ("%d (constant)" % args.const_alpha if 0 <= args.const_alpha <= 255
+                                                                     else "255 (opaque frames, as after cvtColor BGR2RGBA)"),
                        "tolerance_vs_cpu_path": "max |diff| <= %d per output byte" % PARITY_TOL[(args.filter, args.mode)]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -506,7 +511,7 @@ def main(argv=None):
                 line["roofline"]["frac_of_copy_ceiling"] = achieved / copy_gbs
 
         # ---- side figure: the Gaussian's general 4-channel path (non-opaque frames), same run, same pools -----
-        if args.filter == "gauss" and not args.random_alpha and not args.no_side_figures and args.mode == "fast":
+        if args.filter == "gauss" and not args.random_alpha and args.const_alpha < 0 and not args.no_side_figures and args.mode == "fast":
             d_in2 = d_in.clone()
             d_in2[..., 3] = torch.randint(0, 256, (F, h, w), dtype=torch.uint8, device=dev)
             for _ in range(4):

@@ -200,12 +200,12 @@ struct SlideLane {
     uint32_t in_off, out_off;
     int y0, nout, nin, h;
     bool left_of_image, right_of_image, edge_strip, stores;
-    // RAGGED variant (width % 4 != 0 or buffers not 16-byte aligned): in the two edge strips the lanes that overlap the
-    // row's ends address their 4 pixels one by one, clamped to the row (which is also what replicates the edge pixel).
-    // (Round 3 tried one clamped 16-byte load + a shift by v_cndmask for those lanes instead — no divergent branch, no
-    // extra load instructions: 3.5 % SLOWER at width 1023, same box, and -2 % in the pipeline; removed.)
-    uint32_t px_off[4];   // byte offsets of the 4 (clamped) pixels inside a row
+    // RAGGED variant (width % 4 != 0 or buffers not 16-byte aligned): lanes of an edge strip that overlap the row's right
+    // end load the row's last four pixels and shift them into place (slide_common.hpp: RaggedEdge; six v_cndmask per row,
+    // edge strips only, no divergent branch).  Images narrower than 4 pixels keep the per-pixel form (px_off).
+    uint32_t px_off[4];   // w < 4: byte offsets of the 4 (clamped) pixels inside a row
     int x_lane, w;        // first pixel of the lane (may be < 0 or >= w), image width
+    RaggedEdge edge;
 };
 
 // "Do this lane's four pixels all carry alpha A?" as one AND chain: with nA = (A ^ 0xFF) << 24 the top byte of
@@ -260,21 +260,14 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
         if constexpr (R <= 2)  // (k = 9: the asm statements keep hipcc from unrolling the trip; k = 7: -4 %)
             lane_offset_here(in_off);
         if constexpr (RAGGED) {
-            if (L.edge_strip) {  // wave-uniform
-                // only the lanes that overlap the row's ends address their pixels one by one (clamped); the others take
-                // the same unaligned 16-byte access as in interior strips (4 narrow loads for all 64 lanes made the edge
-                // strips — 2 of 5 at width 1023 — cost four times the address work)
+            if (L.w < 4) {  // wave-uniform, tiny images only
                 u32x4 r;
-                if (L.x_lane >= 0 && L.x_lane + 3 < L.w) {
-                    r = gload_a4<u32x4>(rowp + in_off);
-                } else {
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        r[j] = gload<uint32_t>(rowp + L.px_off[j]);
-                }
+                for (int j = 0; j < 4; j++)
+                    r[j] = gload<uint32_t>(rowp + L.px_off[j]);
                 return r;
             }
-            // interior strip: all 4 pixels are inside the row, but the row is only 4-byte aligned
+            // every lane: one 16-byte access inside the row (in_off is clamped to pixel w - 4); the row is only 4-byte aligned
             return gload_a4<u32x4>(rowp + in_off);
         } else {
             // plain (cached) load: the halo lanes' lines are read again by the neighbouring strip
@@ -310,13 +303,17 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
             u32x4 p_copy = q[u];
             u32x4& p = *((PF < K) ? &q[u] : &p_copy);
             q[(u + PF) % K] = load_row(i + PF);
-            if constexpr (!RAGGED) {
-                if (L.edge_strip) {
+            if (L.edge_strip) {  // wave-uniform
+                if constexpr (!RAGGED) {
                     // halo lanes outside the image replicate the edge pixel (clamp-to-edge columns)
                     if (L.left_of_image)
                         p = u32x4{p.x, p.x, p.x, p.x};
                     if (L.right_of_image)
                         p = u32x4{p.w, p.w, p.w, p.w};
+                } else if (L.w >= 4) {
+                    if (L.left_of_image)
+                        p = u32x4{p.x, p.x, p.x, p.x};
+                    ragged_shift_clamp(p, L.edge);  // lanes past the row's end: pixel w - 1 replicated
                 }
             }
             if constexpr (AMODE == 1) {
@@ -497,6 +494,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
     L.fout = uniform_ptr(out + it.frame * L.row_bytes * h);
     L.in_off = (uint32_t)q_load * 16u;
     L.out_off = (uint32_t)(L.stores ? q_lane : 0) * 16u;
+    L.edge = RaggedEdge{false, false, false, false};
+    if constexpr (RAGGED) {
+        if (w >= 4)
+            L.in_off = ragged_edge_setup(q_lane, q_load, w, &L.edge);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++)
         L.px_off[j] = (uint32_t)clampi(4 * q_lane + j, 0, w - 1) * 4u;

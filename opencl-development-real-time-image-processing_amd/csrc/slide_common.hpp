@@ -172,6 +172,41 @@ __device__ __forceinline__ void gstore_a1(global_ptr<uint8_t> p, V v)
     *(global_ptr<VA>)p = v;
 }
 
+// RAGGED rows (width % 4 != 0, or buffers that are not 16-byte aligned): a lane of an edge strip whose four pixels
+// run past the row's right end loads the row's LAST four pixels instead — its load offset is clamped to pixel w - 4 —
+// and moves them into place afterwards: `shift` = how far the lane starts beyond pixel w - 4.  Round 2 addressed those
+// lanes' pixels one by one under a divergent branch: four more load instructions per row for the whole wave, in two
+// strips of five at width 1023.  Same box, same buffers, Gaussian: 1023 x 819 x 2048 frames 4.73 -> 4.89 TB/s, 427 x 640 x
+// 4096 4.90 -> 5.00, 75 x 75 x 65536 1.96 -> 2.06 (profiles/r03_ragged_ab.txt).  Needs w >= 4; narrower images keep the
+// per-pixel form.  Used by gauss_slide.hip only: the same change left Sobel where it was (4.93 / 4.94 TB/s at 1023 x 819,
+// 4.19 / 4.19 at 427 x 640) and cost the fused pipeline 2-3 % (3.84 against 3.91, 3.75 against 3.86), so those two keep
+// the per-pixel loads.  (What does NOT matter for these rows is the alignment of the 16-byte accesses themselves: with
+// every row base rounded down to 16 bytes — wrong pixels, timing only — the ragged Gaussian ran 4.77 against 4.81.)
+struct RaggedEdge {
+    bool sh1, sh2, sh3, sh4;  // shift >= 1, 2, 3, 4
+};
+
+// q_lane = the lane's own quad column (may be < 0 or past the row), q_load = the quad it loads (clamped by the caller).
+// Returns the byte offset of the load inside a row.
+__device__ __forceinline__ uint32_t ragged_edge_setup(int q_lane, int q_load, int w, RaggedEdge* e)
+{
+    const int xs = min(4 * q_load, w - 4);
+    const int shift = 4 * q_lane - xs;  // > 0 only where the lane's pixels run past pixel w - 4
+    e->sh1 = shift >= 1;
+    e->sh2 = shift >= 2;
+    e->sh3 = shift >= 3;
+    e->sh4 = shift >= 4;
+    return (uint32_t)xs * 4u;
+}
+
+// clamp-to-edge columns (Gaussian, the pipeline's gray image): out[j] = in[min(j + shift, 3)] — pixel w - 1 replicated
+__device__ __forceinline__ void ragged_shift_clamp(u32x4& p, const RaggedEdge& e)
+{
+    p.x = e.sh3 ? p.w : (e.sh2 ? p.z : (e.sh1 ? p.y : p.x));
+    p.y = e.sh2 ? p.w : (e.sh1 ? p.z : p.y);
+    p.z = e.sh1 ? p.w : p.z;
+}
+
 // What every sliding kernel starts with: which (frame, band, strip) this wave owns.  Wave-uniform
 // (readfirstlane keeps it in SGPRs).  Returns false for the padding waves of the last block of a phase.
 struct SlideItem {

@@ -8,6 +8,7 @@ row --filter gray1
 row --filter gauss --k 3
 row --filter gauss
 row --filter gauss --random-alpha
+row --filter gauss --const-alpha 128
 row --filter gauss --k 7 --sigma 2.0
 row --filter gauss --k 9 --sigma 2.5
 row --filter gauss --k 11 --sigma 3.0 --frames 64
@@ -23,6 +24,10 @@ row --filter pipeline --width 1023 --height 819 --frames 2048
 row --filter gauss --frames 1 --steps 300
 row --filter gauss --frames 8 --steps 200
 row --filter gauss --frames 64
+# what one rank of an 8-GPU strong-scaling job runs (BASELINE config 5: 64 x 4K through the pipeline), steps scaled to >= 200 ms
+row --filter pipeline --frames 64 --steps 400 --warmup 40
+row --filter pipeline --frames 128 --steps 200 --warmup 20
+row --filter gauss --frames 32 --steps 600 --warmup 60
 # BASELINE.json config 2 and friends: 1080p frames (1024 frames = the 4K batches' byte count)
 row --filter gauss --width 1920 --height 1080 --frames 1024
 row --filter gauss --width 1920 --height 1080 --frames 1024 --random-alpha
