@@ -398,31 +398,40 @@ int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w,
         if (rc != MI355_OK)
             return rc;
     }
+    // Four events on the in-order stream give the six timestamps: write-end IS kernel-start and kernel-end IS
+    // read-start (round 2 recorded six events and made five elapsed-time queries per call; at 75 x 75 the API calls
+    // around the three operations were a third of the call).  No events at all when the caller wants no timestamps.
     hipStream_t s = ctx->stream;
     const uint64_t host0 = now_ns();
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     if (bgr) {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_raw, in, npx * 3, hipMemcpyHostToDevice, s));
     } else {
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, in, in_bytes, hipMemcpyHostToDevice, s));
     }
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     if (bgr)  // the BGR2RGBA expansion counts as kernel time
         HIP_TRY(ctx, launch_bgr_to_rgba(s, static_cast<const uint8_t*>(ctx->d_raw), static_cast<uint8_t*>(ctx->d_in), npx));
     rc = dispatch_dev(ctx, filter, ctx->d_in, ctx->d_out, w, h, nframes, k, sigma);
     if (rc != MI355_OK)
         return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
     if (prof_ns) {
         prof_ns[0] = host0;
+        static const int kEv[6] = {0, 1, 1, 3, 3, 5};
+        float ms1 = 0.0f, ms3 = 0.0f, ms5 = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms1, ctx->ev[0], ctx->ev[1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms3, ctx->ev[0], ctx->ev[3]));
+        HIP_TRY(ctx, hipEventElapsedTime(&ms5, ctx->ev[0], ctx->ev[5]));
         for (int i = 1; i < 6; i++) {
-            float ms = 0.0f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[i]));
+            const float ms = kEv[i] == 1 ? ms1 : (kEv[i] == 3 ? ms3 : ms5);
             prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
         }
     }
