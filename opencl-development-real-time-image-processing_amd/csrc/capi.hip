@@ -22,7 +22,7 @@ struct CoefEntry {
     int k;
     uint32_t sigma_bits;
     GaussCoef coef;
-    float* d_buf;  // [k*k w2d][k w1d][256 constant-alpha bytes << 24, as uint32]
+    float* d_buf;  // [k*k w2d][k w1d][256 constant-alpha bytes << 24, as uint32][256 CPU-chain bytes << 16]
     std::vector<float> h_tab;  // host copy of the same block (its heap storage stays put when entries move)
     uint64_t last_use;
     bool installed;  // came through mi355_ctx_set_gauss_weights: never evicted (it cannot be regenerated)
@@ -201,19 +201,30 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, bool inst
         CoefEntry e{};
         e.k = k;
         e.sigma_bits = fbits(sigma);
-        HIP_TRY(ctx, hipMalloc((void**)&e.d_buf, sizeof(float) * (size_t)(k * k + k + 256)));
+        HIP_TRY(ctx, hipMalloc((void**)&e.d_buf, sizeof(float) * (size_t)(k * k + k + 512)));
         ctx->coefs.push_back(e);
         slot = &ctx->coefs.back();
     }
     slot->last_use = ++ctx->coef_clock;
     slot->installed = slot->installed || installed;
-    std::vector<float> host((size_t)k * k + k + 256);
+    std::vector<float> host((size_t)k * k + k + 512);
     std::memcpy(host.data(), w2d, sizeof(float) * (size_t)k * k);
     const bool separable = separable_factor(k, w2d, host.data() + (size_t)k * k);
     uint32_t alpha_tab[256];
     for (uint32_t a = 0; a < 256; a++)
         alpha_tab[a] = gauss_const_alpha(host.data() + (size_t)k * k, k, a) << 24;
     std::memcpy(host.data() + (size_t)k * k + k, alpha_tab, sizeof(alpha_tab));
+    uint32_t alpha_cpu[256];
+    for (uint32_t a = 0; a < 256; a++) {
+        // the CPU path's own chain over a window that is `a` everywhere (one float multiply, one float add per tap;
+        // this translation unit is built with -ffp-contract=off), clamped and truncated
+        float chain = 0.0f;
+        for (int i = 0; i < k * k; i++)
+            chain += (float)a * w2d[i];
+        chain = chain < 0.0f ? 0.0f : (chain > 255.0f ? 255.0f : chain);
+        alpha_cpu[a] = (uint32_t)chain << 16;
+    }
+    std::memcpy(host.data() + (size_t)k * k + k + 256, alpha_cpu, sizeof(alpha_cpu));
     // blocking copy from pageable memory: the table is live on the device when this returns
     const hipError_t ce = hipMemcpy(slot->d_buf, host.data(), sizeof(float) * host.size(), hipMemcpyHostToDevice);
     if (ce != hipSuccess) {
@@ -229,6 +240,8 @@ int install_coef(mi355_ctx* ctx, int k, float sigma, const float* w2d, bool inst
     slot->coef.d_w1d = slot->d_buf + (size_t)k * k;
     slot->coef.d_alpha_tab = reinterpret_cast<const uint32_t*>(slot->d_buf + (size_t)k * k + k);
     std::memcpy(slot->coef.h_alpha_tab, alpha_tab, sizeof(alpha_tab));
+    slot->coef.d_alpha_cpu = reinterpret_cast<const uint32_t*>(slot->d_buf + (size_t)k * k + k + 256);
+    std::memcpy(slot->coef.h_alpha_cpu, alpha_cpu, sizeof(alpha_cpu));
     std::memset(slot->coef.h_w1d, 0, sizeof(slot->coef.h_w1d));
     std::memcpy(slot->coef.h_w1d, host.data() + (size_t)k * k, sizeof(float) * k);
     slot->h_tab = host;
@@ -362,6 +375,24 @@ int dispatch_dev(mi355_ctx* ctx, int filter, const void* d_in, void* d_out, int 
     return MI355_OK;
 }
 
+// The six timestamps of a write / kernel / read call from the four events recorded around the three operations on the
+// in-order stream (ev[0] before the write, ev[1] between write and kernel, ev[3] between kernel and read, ev[5] after
+// the read): write-end IS kernel-start, kernel-end IS read-start.
+int fill_prof(mi355_ctx* ctx, uint64_t host0, uint64_t prof_ns[6])
+{
+    static const int kEv[6] = {0, 1, 1, 3, 3, 5};
+    float ms1 = 0.0f, ms3 = 0.0f, ms5 = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms1, ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms3, ctx->ev[0], ctx->ev[3]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms5, ctx->ev[0], ctx->ev[5]));
+    prof_ns[0] = host0;
+    for (int i = 1; i < 6; i++) {
+        const float ms = kEv[i] == 1 ? ms1 : (kEv[i] == 3 ? ms3 : ms5);
+        prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
+    }
+    return MI355_OK;
+}
+
 // H2D, kernel, D2H with the reference's six profiling timestamps (RT/src/Controller.cpp:66-74)
 int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w, int h, int nframes,
              int k, float sigma, uint64_t prof_ns[6])
@@ -423,18 +454,8 @@ int run_host(mi355_ctx* ctx, int filter, const uint8_t* in, uint8_t* out, int w,
     if (prof_ns)
         HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (prof_ns) {
-        prof_ns[0] = host0;
-        static const int kEv[6] = {0, 1, 1, 3, 3, 5};
-        float ms1 = 0.0f, ms3 = 0.0f, ms5 = 0.0f;
-        HIP_TRY(ctx, hipEventElapsedTime(&ms1, ctx->ev[0], ctx->ev[1]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ms3, ctx->ev[0], ctx->ev[3]));
-        HIP_TRY(ctx, hipEventElapsedTime(&ms5, ctx->ev[0], ctx->ev[5]));
-        for (int i = 1; i < 6; i++) {
-            const float ms = kEv[i] == 1 ? ms1 : (kEv[i] == 3 ? ms3 : ms5);
-            prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
-        }
-    }
+    if (prof_ns)
+        return fill_prof(ctx, host0, prof_ns);
     return MI355_OK;
 }
 
@@ -672,25 +693,21 @@ MI355_API int mi355_image2d_rgba8(mi355_ctx* ctx, int filter, const uint8_t* rgb
     }
     hipStream_t s = ctx->stream;
     const uint64_t host0 = now_ns();
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[0], s));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_in, rgba, in_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[2], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[1], s));
     HIP_TRY(ctx, launch_image2d(s, filter, static_cast<const uint8_t*>(ctx->d_in), static_cast<uint8_t*>(ctx->d_out), w, h, 1,
                                 k, ctx->d_img_table));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[4], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[3], s));
     HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_out, out_bytes, hipMemcpyDeviceToHost, s));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
+    if (prof_ns)
+        HIP_TRY(ctx, hipEventRecord(ctx->ev[5], s));
     HIP_TRY(ctx, hipStreamSynchronize(s));
-    if (prof_ns) {
-        prof_ns[0] = host0;
-        for (int i = 1; i < 6; i++) {
-            float ms = 0.0f;
-            HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[i]));
-            prof_ns[i] = host0 + (uint64_t)((double)ms * 1.0e6);
-        }
-    }
+    if (prof_ns)
+        return fill_prof(ctx, host0, prof_ns);
     return MI355_OK;
 }
 

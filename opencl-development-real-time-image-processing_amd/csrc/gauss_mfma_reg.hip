@@ -86,7 +86,8 @@ __device__ __forceinline__ float residual_r(uint32_t hp, float v)
 template <bool CLAMP>
 __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t* __restrict__ in,
                                                                   uint8_t* __restrict__ out, int w, int h, RPlan plan,
-                                                                  RWeights W, float alpha_top, float plane_bias)
+                                                                  RWeights W, float alpha_top, float plane_bias, float hsum,
+                                                                  const uint32_t* __restrict__ alpha_cpu)
 {
     __shared__ float wtab[2 * kTapPadR];  // wtab[kTapPadR + d] = 256 * w(d), zero beyond the radius
     __shared__ __attribute__((aligned(16))) uint32_t otile[2][16][kOutPitchR];  // two output tiles, 8,704 B
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
     // 4g+2, 4g+3) of vector c >> 1.  (Vectors, not arrays: hipcc left a struct of arrays in scratch memory.)
     struct HTile {
         u32x4 hi[2], lo[2];
-        bool clear;  // wave-uniform: some staged pixel was not opaque
+        int alpha;  // wave-uniform: the alpha value every staged pixel of the tile carries (0..255), or -1 (mixed)
     };
 
     // Per wave: every pixel of the 32-pixel window inside the image (INTERIOR) or not; two instantiations entered
@@ -180,10 +181,24 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
         };
         // pass 1 of one tile.  The alpha operand is 255 - A (0x64FF64FF minus the gathered bytes, no borrow): an opaque
         // window blurs to exactly 0 and its alpha is the host-evaluated constant (launch_gauss_mfma_reg).
-        auto pass1 = [&](Staged& st, HTile& t) __attribute__((always_inline)) {
+        // probe (wave-uniform): whether a tile that is not opaque is examined for ONE other alpha value.  Frames whose alpha
+        // varies from pixel to pixel would pay the examination (an OR chain, two compares, a ballot) on every tile for
+        // nothing (-1.9 % at k = 17 when every fourth tile was examined), so a wave examines the first tile of its band and
+        // every tile that follows a constant one: a band that meets mixed alpha stays on the general path to its end.
+        auto pass1 = [&](Staged& st, HTile& t, bool probe) __attribute__((always_inline)) {
             to_matrix_lanes(st);
             const uint32_t a = st.lo[0] & st.lo[1] & st.lo[2] & st.lo[3] & st.hi[0] & st.hi[1] & st.hi[2] & st.hi[3];
-            t.clear = __builtin_amdgcn_ballot_w64(a < 0xFF000000u) != 0;
+            t.alpha = 255;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(a < 0xFF000000u) != 0, 0)) {  // wave-uniform: not opaque — one other value, or mixed?
+                t.alpha = -1;
+                if (probe) {
+                    const uint32_t o = st.lo[0] | st.lo[1] | st.lo[2] | st.lo[3] | st.hi[0] | st.hi[1] | st.hi[2] | st.hi[3];
+                    const uint32_t a0 = ((uint32_t)__builtin_amdgcn_readfirstlane((int)a) >> 24) & 0xFFu;
+                    const bool differs = ((a >> 24) != a0) | ((o >> 24) != a0);  // AND and OR of the alphas both a0 <=> all are
+                    if (__builtin_amdgcn_ballot_w64(differs) == 0)
+                        t.alpha = (int)a0;
+                }
+            }
             // pixel pairs deinterleaved once: rb[i] = (R0, R1, B0, B1), ga[i] = (G0, G1, A0, A1) of pixels 2i, 2i + 1
             uint32_t rb[4], ga[4];
 #pragma unroll
@@ -194,8 +209,17 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
             }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (c == 3 && !t.clear) {  // wave-uniform
+                if (c == 3 && t.alpha == 255) {  // wave-uniform: the plane 255 - A of an opaque tile is 0
                     t.hi[1][2] = t.hi[1][3] = t.lo[1][2] = t.lo[1][3] = 0u;
+                    continue;
+                }
+                if (c == 3 && __builtin_expect(t.alpha >= 0, 0)) {  // wave-uniform: ... and that of a constant-alpha tile blurs to a constant,
+                    // 256 * (255 - A) * sum of the 17 split weights; only a block whose OTHER tile is mixed ever reads it
+                    const float hc = (float)(255 - t.alpha) * hsum;
+                    const uint32_t hp = pk16r(hc, hc);
+                    const uint32_t lp = pk16r(residual_r<0>(hp, hc), residual_r<1>(hp, hc));
+                    t.hi[1][2] = t.hi[1][3] = hp;
+                    t.lo[1][2] = t.lo[1][3] = lp;
                     continue;
                 }
                 // channel c of pixel pair i sits in bytes (c >> 1) * 2, (c >> 1) * 2 + 1 of rb[i] (c even) / ga[i] (c odd);
@@ -224,14 +248,18 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
         };
         // pass 2 of output block b (rows yb0 + 16 b ..) from the H tiles b (up) and b + 1 (dn), and its store
         auto pass2 = [&](const HTile& up, const HTile& dn, int b) __attribute__((always_inline)) {
-            const bool opaque = !up.clear && !dn.clear;  // wave-uniform
+            // wave-uniform: both tiles carry ONE alpha value -> the block's alpha is the CPU chain's byte for it (table)
+            const bool const_alpha = up.alpha >= 0 && up.alpha == dn.alpha;
+            uint32_t alpha_out = alpha_const;
+            if (__builtin_expect(const_alpha && up.alpha != 255, 0))
+                alpha_out = __builtin_amdgcn_readfirstlane(alpha_cpu[up.alpha]);
             uint32_t u[4][4];
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                if (c == 3 && opaque) {
+                if (c == 3 && const_alpha) {
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        u[3][e] = alpha_const;
+                        u[3][e] = alpha_out;
                     continue;
                 }
                 const int vi = c >> 1, e0 = 2 * (c & 1);
@@ -281,12 +309,13 @@ __global__ __launch_bounds__(kThreadsR) void gauss_mfma_reg_kernel(const uint8_t
 
         Staged stA, stB;
         HTile hA, hB;
+        hA.alpha = hB.alpha = -1;
         load_tile(0, stA);
         load_tile(1, stB);
         // step j: tile j arrives in `st` (loaded two steps ago), its registers are refilled with tile j + 2 as soon as
         // the operands are built; output block j - 1 = tiles j - 1 (`up`) and j (`cur`)
         auto step = [&](int j, Staged& st, HTile& cur, const HTile& up) __attribute__((always_inline)) {
-            pass1(st, cur);
+            pass1(st, cur, j == 0 || up.alpha >= 0);
             if (j + 2 <= nb)
                 load_tile(j + 2, st);
             if (j >= 1)
@@ -370,12 +399,15 @@ hipError_t launch_gauss_mfma_reg(hipStream_t stream, const uint8_t* d_in, uint8_
         bsum += (double)(float)hi + (double)(float)lo;
     }
     const float plane_bias = (float)(-1024.0 * bsum);
+    const float hsum = (float)bsum;  // a constant plane v blurs (pass 1) to v * hsum
+    if (!coef.d_alpha_cpu)
+        return hipErrorInvalidValue;
     if (clamp)
         hipLaunchKernelGGL(gauss_mfma_reg_kernel<true>, dim3(plan.nwork), dim3(kThreadsR), 0, stream, d_in, d_out, w, h,
-                           plan, W, alpha_top, plane_bias);
+                           plan, W, alpha_top, plane_bias, hsum, coef.d_alpha_cpu);
     else
         hipLaunchKernelGGL(gauss_mfma_reg_kernel<false>, dim3(plan.nwork), dim3(kThreadsR), 0, stream, d_in, d_out, w, h,
-                           plan, W, alpha_top, plane_bias);
+                           plan, W, alpha_top, plane_bias, hsum, coef.d_alpha_cpu);
     return hipGetLastError();
 }
 

@@ -25,6 +25,11 @@ struct GaussCoef {
     // (gauss_const_alpha).  The constant-alpha fast path of the sliding-window kernels reads it.
     const uint32_t* d_alpha_tab;
     uint32_t h_alpha_tab[256];
+    // alpha_cpu[A] = (the CPU path's byte for a channel whose whole k x k window holds A — its own k*k-term float chain,
+    // src/GaussianBlur/GaussianBlur.cpp:243-256) << 16: what the matrix-core kernel stores for constant-alpha windows
+    // (its alpha = 255 constant since round 2, now for every A).
+    const uint32_t* d_alpha_cpu;
+    uint32_t h_alpha_cpu[256];
 };
 
 // The FAST arithmetic's result for one channel of a pixel whose k x k window holds the value `a` everywhere:

@@ -66,6 +66,55 @@ def test_mfma_full_frames(mfma, oracle):
     _check(mfma.gauss(noisy, 17, 6.0), oracle.gauss_rgba(noisy, 17, 6.0, threads=16))
 
 
+@pytest.mark.parametrize("k,sigma", [(7, 2.0), (17, 6.0)])
+def test_mfma_constant_and_piecewise_constant_alpha(mfma, oracle, k, sigma):
+    """The matrix-core kernel recognises tiles whose alpha is ONE value (not only 255): a block between two such tiles of
+    the same value stores the CPU chain's byte for an all-A window (no alpha plane, no matrix work for it), and a
+    constant tile next to a mixed one contributes its — constant — alpha plane.  Constants, a horizontal and a vertical
+    edge on and off the 16-row / 16-pixel tile boundaries, a block with a hole, one stray pixel: within 1 LSB of the
+    CPU path everywhere, alpha included."""
+    h, w = 200, 320
+    base = oracle.synth_rgba(w, h, 1, first_frame=k, mode=0)[0]
+    cases = {}
+    for a in (0, 1, 128, 254):
+        img = base.copy()
+        img[..., 3] = a
+        cases["const %d" % a] = img
+    img = base.copy()
+    img[96:, :, 3] = 128          # edge on a tile boundary
+    cases["rows 96"] = img
+    img = base.copy()
+    img[101:, :, 3] = 7           # edge inside a tile
+    cases["rows 101"] = img
+    img = base.copy()
+    img[:, :160, 3] = 33          # vertical edge on a 16-pixel column boundary
+    cases["cols 160"] = img
+    img = base.copy()
+    img[:, :165, 3] = 33
+    cases["cols 165"] = img
+    img = base.copy()
+    img[..., 3] = 200
+    img[50:120, 60:200, 3] = 64
+    img[70:80, 100:110, 3] = 255
+    cases["block"] = img
+    img = base.copy()
+    img[..., 3] = 90
+    img[131, 47, 3] = 91          # one stray pixel in a constant frame
+    cases["stray"] = img
+    for name, img in cases.items():
+        got = mfma.gauss(img, k, sigma)
+        ref = oracle.gauss_rgba(img, k, sigma)
+        d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
+        assert d.max() <= 1, (name, int(d.max()))
+        # the alpha of a constant frame is the CPU path's own byte, exactly
+        if name.startswith("const"):
+            assert np.array_equal(got[..., 3], ref[..., 3]), name
+    frames = np.stack([cases["const 128"], cases["block"], base, cases["rows 101"]])
+    got = mfma.gauss(frames, k, sigma)
+    for f in range(4):
+        _check(got[f], oracle.gauss_rgba(frames[f], k, sigma), rate=1.0)
+
+
 def test_mfma_falls_back_where_it_does_not_apply(mfma, pkg, oracle):
     """Widths that are not multiples of 4, k > 17, EXACT mode: IMPL_MFMA behaves like AUTO."""
     img = rand_rgba(33, 251, seed=5, alpha=None)
