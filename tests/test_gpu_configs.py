@@ -586,7 +586,7 @@ def test_exact_mode_sliding_kernel(ctx, pkg, oracle, k, sigma, h, w):
     path (src/GaussianBlur/GaussianBlur.cpp:234-261) and to the tiled EXACT kernel, on noise, opaque and flat frames."""
     ctx.set_gauss_mode(pkg.GAUSS_EXACT)
     try:
-        for case in ("noise", "opaque", "one_hole", "flat"):
+        for case in ("noise", "opaque", "one_hole", "flat", "alpha_0", "alpha_128", "alpha_split"):
             if case == "noise":
                 img = rand_rgba(h, w, seed=h + w + k, alpha=None)
             elif case == "flat":
@@ -596,6 +596,13 @@ def test_exact_mode_sliding_kernel(ctx, pkg, oracle, k, sigma, h, w):
                 img = oracle.synth_rgba(w, h, 1, first_frame=k, mode=1)[0].copy()   # A = 255
                 if case == "one_hole":
                     img[h // 2, (w * 3) // 4, 3] = 9
+                elif case == "alpha_0":          # constant alpha other than 255: the 3-channel walk with the CPU
+                    img[..., 3] = 0              # chain's byte for an all-A window (round 3)
+                elif case == "alpha_128":
+                    img[..., 3] = 128
+                elif case == "alpha_split":      # two constants: bands that meet both fall back to four channels
+                    img[..., 3] = 200
+                    img[h // 2:, :, 3] = 31
             ref = oracle.gauss_rgba(img, k, sigma, threads=8)
             assert np.array_equal(ctx.gauss(img, k, sigma), ref), case
             ctx.set_impl(pkg.IMPL_TILE)
