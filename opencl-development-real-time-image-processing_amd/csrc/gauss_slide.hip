@@ -227,6 +227,7 @@ __device__ __forceinline__ bool alpha_row_differs(const u32x4& p, uint32_t nA)
 constexpr int kBandDone = 0;          // every output row stored
 constexpr int kBandAbortUniform = 1;  // AMODE 1: a row whose alpha is uniform over the strip but not 255 — worth AMODE 2
 constexpr int kBandAbort = 2;         // a row with mixed alphas, or (AMODE 2) a window that spans two values: 4 channels
+constexpr int kBandAbortUniformFirst = 3;  // kBandAbortUniform at the band's first row: q3[0 .. PF-1] still hold the first rows
 
 // AMODE of a 3-channel pass: 1 = alpha 255 only — the hot loop of opaque frames, exactly round 2's instruction stream —;
 // 2 = any constant, piecewise (value tracking, table loads, window check).  The kernel tries 1, then 2 only where 1
@@ -241,7 +242,8 @@ constexpr int kBandAbort = 2;         // a row with mixed alphas, or (AMODE 2) a
 // the caller redoes the band with NCH = 4.
 template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP, int AMODE>
 __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi,
-                                                const uint32_t* __restrict__ alpha_tab)
+                                                const uint32_t* __restrict__ alpha_tab, u32x4 (&q3)[2 * R + 1],
+                                                bool preloaded)
 {
     constexpr int K = 2 * R + 1;
     static_assert((NCH == 4) == (AMODE == 0), "AMODE 1 / 2 belong to the 3-channel pass");
@@ -278,10 +280,16 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
     // prefetch ring: row i lives in slot i % K; its load is issued PF rows before it is consumed, so
     // only PF of the K slots are live at a time (PF x 1 KiB in flight per wave)
     constexpr int PF = (K < 3) ? K : 3;
-    u32x4 q[K];
+    // The 3-channel passes share the kernel's ring q3: when the alpha = 255 pass stops at the band's FIRST row the
+    // constant-alpha pass starts from the rows already in flight (AMODE 2, preloaded) instead of a second start-up per
+    // band.  The 4-channel pass keeps a ring of its own (sharing it too cost 12 VGPRs).
+    u32x4 q_own[K];
+    u32x4 (&q)[K] = (AMODE == 0) ? q_own : q3;
+    if (AMODE != 2 || !preloaded) {
 #pragma unroll
-    for (int u = 0; u < PF; u++)
-        q[u] = load_row(u);
+        for (int u = 0; u < PF; u++)
+            q[u] = load_row(u);
+    }
 
     // k <= 7: ring of the last K input rows, converted to float once (row i lives in slot i % K, static after
     // unrolling); the vertical sums of an output row are formed when its window is complete — in either walking
@@ -319,7 +327,9 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
             if constexpr (AMODE == 1) {
                 if (alpha_row_differs<true>(p, 0u)) {  // wave-uniform: the pass ends here
                     const uint32_t a_row = ((uint32_t)__builtin_amdgcn_readfirstlane((int)p.x) >> 24) & 0xFFu;
-                    return alpha_row_differs<false>(p, (a_row ^ 0xFFu) << 24) ? kBandAbort : kBandAbortUniform;
+                    if (alpha_row_differs<false>(p, (a_row ^ 0xFFu) << 24))
+                        return kBandAbort;
+                    return (i == 0 && PF < K) ? kBandAbortUniformFirst : kBandAbortUniform;  // (k = 3: slot 0 is refilled already)
                 }
             }
             if constexpr (AMODE == 2) {
@@ -519,35 +529,38 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
     // each needs from the other) at the same moment and the second reader hits L2 (sobel_slide.hip does the
     // same; measured there: HBM reads -12 %).  Wave-uniform: two instantiations of the band code.
     const bool up = (it.band & 1) != 0;
-    auto run = [&](auto amode) -> int {
+    u32x4 q3[K];  // the 3-channel passes' ring of input rows
+    auto run = [&](auto amode, bool preloaded) -> int {
         constexpr int AMODE = decltype(amode)::value;
         constexpr int NCH = AMODE == 0 ? 4 : 3;
         if constexpr (R <= 3) {  // (the k = 9 form walks down only)
             if (up)
-                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true, AMODE>(L, wv, alpha_hi, alpha_tab);
+                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true, AMODE>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
         }
-        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false, AMODE>(L, wv, alpha_hi, alpha_tab);
+        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false, AMODE>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
     };
     // 3 channels while alpha is 255; where that stops at a row of another UNIFORM alpha, 3 channels with the value
-    // tracked (constant and piecewise-constant alpha); 4 channels for what is left.  Every pass starts the band over:
-    // the rows an earlier pass stored are rewritten with the same bytes.  (Handing the rows already in flight from an
-    // aborted pass to the next was tried in round 3: no gain on alpha-noise frames — the second start-up hits L1 — and
-    // 12 more VGPRs, which cost the ragged instantiation its fourth wave.)
+    // tracked (constant and piecewise-constant alpha); 4 channels for what is left.  A pass that stops hands the band to
+    // the next one, which starts it over: the rows an earlier pass stored are rewritten with the same bytes.  Only the
+    // hand-over from the alpha = 255 pass to the constant-alpha pass at the band's FIRST row keeps the rows in flight
+    // (q3; +0.8 % on constant-alpha frames).  Sharing the ring with the 4-channel pass as well cost 12 VGPRs — the ragged
+    // instantiation's fourth wave — and a kernel-level "look at the first row, then pick the pass" loop around single
+    // call sites sent the register allocator to 191-224 VGPRs on the ragged instantiations; both removed.
     auto three_channels = [&]() -> int {
-        int code = run(std::integral_constant<int, 1>{});
-        if (code == kBandAbortUniform)
-            code = run(std::integral_constant<int, 2>{});
+        int code = run(std::integral_constant<int, 1>{}, false);
+        if (code == kBandAbortUniform || code == kBandAbortUniformFirst)
+            code = run(std::integral_constant<int, 2>{}, code == kBandAbortUniformFirst);
         return code;
     };
     if constexpr (MODE == 0) {
         if (three_channels() != kBandDone)
-            run(std::integral_constant<int, 0>{});
+            run(std::integral_constant<int, 0>{}, false);
     } else if constexpr (MODE == 3) {
         const int code = three_channels();
         if (lane == 0)
             flags[it.work] = code == kBandDone ? 0u : 1u;
     } else {
-        run(std::integral_constant<int, 0>{});
+        run(std::integral_constant<int, 0>{}, false);
     }
 }
 
