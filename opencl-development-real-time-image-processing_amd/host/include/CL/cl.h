@@ -15,6 +15,12 @@
  *              clReleaseContext clReleaseMemObject clReleaseSampler
  *              (RT/RealtimeImageProcessing.cpp:282-285,423-426; RT/src/ProgramHandler.cpp:62,85;
  *               RT/src/InfoPlatform.cpp:65,75; RT/src/Controller.cpp:199-232)
+ *
+ * No image entry points (clCreateImage2D, clEnqueueReadImage, clEnqueueWriteImage) exist here:
+ * clGetDeviceInfo(CL_DEVICE_IMAGE_SUPPORT) answers CL_FALSE unless the host process opts in with
+ * MI355_CL_IMAGE_SUPPORT=1, and even then only the bundled Controller's image2d_t code path is backed
+ * (it calls mi355_image2d_rgba8 directly) — code that trusts the capability bit to create cl images
+ * itself would not link (INTEGRATION.md "image2d_t mode").
  */
 #ifndef MI355_CL_SHAPED_H
 #define MI355_CL_SHAPED_H
