@@ -41,6 +41,8 @@ def workload_parser():
     p.add_argument("--alpha-split", action="store_true", help="alpha 255 in the top half of each frame, 128 below, "
                    "and a 200 x 200 block of 64 in the middle: piecewise-constant alpha (a matte)")
     p.add_argument("--photo", default="")
+    p.add_argument("--then-alpha", type=int, default=-1, help="after the rounds, overwrite alpha with this constant IN THE SAME "
+                   "buffers and time the builds again (same placement for both measurements)")
     return p
 
 
@@ -150,10 +152,29 @@ def main():
                 res[label].append(algo / (ms * 1e-3) / 1e12)
                 if label not in sums:
                     sums[label] = "%016x" % ctx.checksum_dev(d_out.data_ptr(), d_out.numel())
+        if a.then_alpha >= 0:
+            d_in[..., 3] = a.then_alpha
+            torch.cuda.synchronize(dev)
+            res2 = {label: [] for label, _ in builds}
+            for _ in range(hargs.rounds):
+                for label, ctx in builds:
+                    for _ in range(hargs.warm):
+                        ctx.filter_dev(filt, d_in.data_ptr(), d_out.data_ptr(), w, h, F, a.k, a.sigma)
+                    torch.cuda.synchronize(dev)
+                    ctx.timer_begin()
+                    for _ in range(hargs.launches):
+                        ctx.filter_dev(filt, d_in.data_ptr(), d_out.data_ptr(), w, h, F, a.k, a.sigma)
+                    res2[label].append(algo / (ctx.timer_end() / hargs.launches * 1e-3) / 1e12)
+            for label in res2:
+                res[label + " | same buffers, alpha=%d" % a.then_alpha] = res2[label]
+                sums[label + " | same buffers, alpha=%d" % a.then_alpha] = "-"
+            builds_print = [(l, None) for l in res]
+        else:
+            builds_print = builds
         print("== " + (" ".join(s) or "(default workload)"), flush=True)
-        for label, _ in builds:
+        for label, _ in builds_print:
             v = res[label]
-            print("  %-24s median %.3f TB/s (%.3f of 8)   rounds %s   checksum %s" %
+            print("  %-44s median %.3f TB/s (%.3f of 8)   rounds %s   checksum %s" %
                   (label, statistics.median(v), statistics.median(v) / 8.0, " ".join("%.3f" % x for x in v), sums[label]),
                   flush=True)
         del d_in, d_out
