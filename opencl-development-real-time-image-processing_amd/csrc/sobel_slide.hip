@@ -194,6 +194,22 @@ __device__ __forceinline__ float dpp_right_or(float v, float edge)
                                                                  __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, false));
 }
 
+// Luminance of ONE wave-uniform pixel on the scalar unit (the two halo pixels of the strip kernel below): S, the quotient
+// S / 1000 and the exception test of luma_quad_int (common.hpp) in s_bfe / s_mul / s_mul_hi — the VALU, which this kernel
+// keeps 74 % busy, sees none of it.  The exception (S a multiple of 1000: 0.1 % of colours, every gray one) takes the
+// table / FP64 form under a wave-uniform branch.  px must be wave-uniform (v_readfirstlane'd by the caller).
+__device__ __forceinline__ uint32_t luma_px_uniform(uint32_t px, const uint8_t* gray_lut)
+{
+    const uint32_t r = px & 0xFFu, g = (px >> 8) & 0xFFu, b = (px >> 16) & 0xFFu;
+    const uint32_t S = 299u * r + 587u * g + 114u * b;  // <= 255000
+    constexpr uint32_t M = 4294968u;                    // ceil(2^32 / 1000)
+    uint32_t q = (uint32_t)(((uint64_t)S * M) >> 32);
+    const uint32_t low = S * M;                         // low half: < 1,000,000 exactly when S % 1000 == 0
+    if (low < 1000000u)                                 // wave-uniform
+        q = __builtin_amdgcn_readfirstlane(luma_px_ambiguous(px, gray_lut));
+    return q;
+}
+
 // The aligned shape (width % 4 == 0, 16-byte-aligned input, 4-byte-aligned output): a wave owns exactly 64 pixel
 // quads — all 64 lanes produce output, the row accesses are whole aligned 1-KiB loads and 256-byte stores like
 // gray.hip's strip kernel — and the one pixel it needs on either side of its strip is fetched separately: a
@@ -250,7 +266,11 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
         qr[u] = load_row(u);
 
     float L[K][4] = {};
-    float HL[K] = {}, HR[K] = {};  // luminance of the two halo pixels, same ring
+    // luminance of the two halo pixels, same ring — wave-uniform integers in SGPRs: the halo columns' share of the
+    // stencil (cs = 2 m + t + b, cd = b - t) is scalar arithmetic too, and only its four results are converted for the
+    // lanes at the strip's ends (round 2 computed both luminances and both column sums on the VALU in every lane: ~24
+    // of 125 instructions per wave-row)
+    int HL[K] = {}, HR[K] = {};
 
     for (int base = 0; base < nin; base += K) {
 #pragma unroll
@@ -259,8 +279,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
             const Row r = qr[u];
             qr[(u + PF) % K] = load_row(i + PF);
             luma_quad_fast(r.p, L[u], gray_lut, gray_run);
-            HL[u] = luma_px_fast(r.hl);
-            HR[u] = luma_px_fast(r.hr);
+            HL[u] = (int)luma_px_uniform((uint32_t)__builtin_amdgcn_readfirstlane((int)r.hl), gray_lut);
+            HR[u] = (int)luma_px_uniform((uint32_t)__builtin_amdgcn_readfirstlane((int)r.hr), gray_lut);
 
             const int st = (u + 1) % K, sm = (u + 2) % K, sb = u;  // oldest, middle, newest row
             float cs[4], cd[4];
@@ -269,8 +289,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_strip_kernel(
                 cs[j] = __builtin_fmaf(2.0f, L[sm][j], L[st][j]) + L[sb][j];
                 cd[j] = L[sb][j] - L[st][j];
             }
-            const float csL = __builtin_fmaf(2.0f, HL[sm], HL[st]) + HL[sb], cdL = HL[sb] - HL[st];
-            const float csR = __builtin_fmaf(2.0f, HR[sm], HR[st]) + HR[sb], cdR = HR[sb] - HR[st];
+            const float csL = (float)(2 * HL[sm] + HL[st] + HL[sb]), cdL = (float)(HL[sb] - HL[st]);
+            const float csR = (float)(2 * HR[sm] + HR[st] + HR[sb]), cdR = (float)(HR[sb] - HR[st]);
             const float csl = dpp_left_or(cs[3], csL), cdl = dpp_left_or(cd[3], cdL);
             float csr = dpp_right_or(cs[0], csR), cdr = dpp_right_or(cd[0], cdR);
             if (partial) {  // the strip ends inside the wave: its last lane takes the halo column too
