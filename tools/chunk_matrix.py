@@ -26,6 +26,24 @@ def main():
     for _ in range(30):
         ctx.filter_dev(filt, d_in.data_ptr(), d_out.data_ptr(), w, h, N * S, 5, 1.5)
     print("rows = input slice, columns = output slice; TB/s (8 B/px), 32 x 4K frames per launch, 20 launches each")
+    extra = [x for x in sys.argv[2:]]   # more builds of the library: their column profile on the SAME pools
+    if extra:
+        ctxs = [("B", ctx)] + [(os.path.basename(x), pkg.Context(0, stream=stream.cuda_stream, lib=pkg.imgfilter.load_library(os.path.join(ROOT, x)))) for x in extra]
+        print("input slice 0 -> output slice j, per build (same pools):")
+        for name, c in ctxs:
+            row = []
+            for j in range(N):
+                a, b = d_in.data_ptr(), d_out.data_ptr() + j * per
+                for _ in range(5):
+                    c.filter_dev(filt, a, b, w, h, S, 5, 1.5)
+                torch.cuda.synchronize(dev)
+                c.timer_begin()
+                for _ in range(20):
+                    c.filter_dev(filt, a, b, w, h, S, 5, 1.5)
+                ms = c.timer_end() / 20
+                row.append(8 * S * w * h / (ms * 1e-3) / 1e12)
+            print("%-20s " % name + " ".join("%.3f" % r for r in row), flush=True)
+        return
     for i in range(N):
         row = []
         for j in range(N):
