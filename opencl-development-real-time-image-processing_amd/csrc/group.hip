@@ -169,12 +169,17 @@ MI355_API int mi355_group_create(int ndev, const int* devices, mi355_group** out
     mi355_group* g = new (std::nothrow) mi355_group();
     if (!g)
         return MI355_ERR_NOMEM;
-    for (int i = 0; i < ndev; i++) {
-        auto mb = std::make_unique<Member>();
-        mb->device = devices ? devices[i] : i;
-        Member* raw = mb.get();
-        mb->th = std::thread([raw] { raw->loop(); });
-        g->members.push_back(std::move(mb));
+    try {  // nothing may throw across the C boundary: a failed allocation or thread start is an error code
+        for (int i = 0; i < ndev; i++) {
+            auto mb = std::make_unique<Member>();
+            mb->device = devices ? devices[i] : i;
+            Member* raw = mb.get();
+            mb->th = std::thread([raw] { raw->loop(); });
+            g->members.push_back(std::move(mb));
+        }
+    } catch (...) {
+        mi355_group_destroy(g);
+        return MI355_ERR_NOMEM;
     }
     // every member creates its context on its own worker thread (the thread that will drive that GPU)
     const int rc = g->all([](Member& mb, int) { return mi355_ctx_create(mb.device, &mb.ctx); });
