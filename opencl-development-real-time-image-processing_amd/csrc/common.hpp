@@ -296,12 +296,30 @@ __device__ __forceinline__ uint64_t fmix64(uint64_t k)
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (observed round-robin
 // placement, speed only), so give each of the 8 residue classes one contiguous chunk of the
 // logical tile list; neighbouring tiles (shared halo rows/columns) then meet in one L2.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk)
+__device__ __forceinline__ uint32_t xcd_remap_contiguous(uint32_t bid, uint32_t nblk)
 {
     const uint32_t q = nblk >> 3, r = nblk & 7u;
     const uint32_t xcd = bid & 7u, idx = bid >> 3;
     const uint32_t base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
     return base + idx;
+}
+
+// kXcdRun > 0: the list is cut into groups of 8 runs of kXcdRun blocks and XCD x takes run x of every group, so the eight
+// XCDs work on eight NEIGHBOURING runs at a time instead of eight regions an eighth of the batch (1 GiB) apart; the
+// remainder of the list keeps the contiguous mapping.  Bijective.  0 = contiguous mapping everywhere.
+constexpr uint32_t kXcdRun = 0;
+
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nblk)
+{
+    if constexpr (kXcdRun == 0) {
+        return xcd_remap_contiguous(bid, nblk);
+    } else {
+        const uint32_t full = nblk / (8u * kXcdRun) * (8u * kXcdRun);
+        if (bid >= full)
+            return full + xcd_remap_contiguous(bid - full, nblk - full);
+        const uint32_t xcd = bid & 7u, idx = bid >> 3;
+        return ((idx / kXcdRun) * 8u + xcd) * kXcdRun + idx % kXcdRun;
+    }
 }
 
 }  // namespace mi355
