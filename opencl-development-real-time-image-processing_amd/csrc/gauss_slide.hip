@@ -240,7 +240,7 @@ constexpr int kBandAbortUniformFirst = 3;  // kBandAbortUniform at the band's fi
 // row; the value changes through a scalar branch and one s_load).  A row with mixed alphas, or an output row whose window
 // spans two values, ends the pass before that row has stored anything: the rows stored so far are correct, and
 // the caller redoes the band with NCH = 4.
-template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP, int AMODE>
+template <int R, bool CLAMP, int NCH, bool RAGGED, bool UP, int AMODE, bool LOCKSTEP>
 __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float (&wv)[2 * R + 1], uint32_t alpha_hi,
                                                 const uint32_t* __restrict__ alpha_tab, u32x4 (&q3)[2 * R + 1],
                                                 bool preloaded)
@@ -310,6 +310,16 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
             // cost two v_mov_b64 per row on every strip for the sake of the edge strips' replication
             u32x4 p_copy = q[u];
             u32x4& p = *((PF < K) ? &q[u] : &p_copy);
+            if constexpr (LOCKSTEP) {
+                // Adjacent strips of a row-band in step: the four waves' 1-KiB accesses to one row reach memory together
+                // (+1.3 % on opaque 4K and 1080p batches, +1.2 % at k = 3, +1.5 % on 8- and 64-frame launches, same box
+                // and buffers; nothing on the issue-bound 4-channel pass or at k >= 7).  A wave that leaves the loop (end
+                // of band, a pass that stops) just stops arriving: s_barrier waits for the waves of the group that have
+                // not terminated, and every wave either reaches another s_barrier of this loop — in whichever pass — or
+                // ends, so nobody waits for ever.  A template parameter, not a flag: the scalar test of a flag in this
+                // loop cost launches of one or two frames 1.4 %.
+                __builtin_amdgcn_s_barrier();
+            }
             q[(u + PF) % K] = load_row(i + PF);
             if (L.edge_strip) {  // wave-uniform
                 if constexpr (!RAGGED) {
@@ -464,7 +474,7 @@ __device__ __forceinline__ int gauss_slide_band(const SlideLane& L, const float 
 // are allocated per kernel, and the opaque pass alone needs 139 instead of 173 VGPRs at k = 7 (3 waves/SIMD
 // instead of 2).  Kernel MODE 3 leaves flags[work] = 0 (band done) or 1; kernel MODE 4 redoes the flagged bands
 // and exits at once everywhere else (gauss_wide.hip does the same).
-template <int R, bool CLAMP, bool RAGGED, int MODE>
+template <int R, bool CLAMP, bool RAGGED, int MODE, bool LOCKSTEP>
 __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1) void gauss_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
     BandPlan plan, Weights<2 * R + 1> wts, uint32_t alpha_hi, const uint32_t* __restrict__ alpha_tab,
@@ -535,9 +545,9 @@ __global__ __launch_bounds__(kWavesPerBlock * 64, (R == 3 && MODE == 3) ? 3 : 1)
         constexpr int NCH = AMODE == 0 ? 4 : 3;
         if constexpr (R <= 3) {  // (the k = 9 form walks down only)
             if (up)
-                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true, AMODE>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
+                return gauss_slide_band<R, CLAMP, NCH, RAGGED, true, AMODE, LOCKSTEP>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
         }
-        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false, AMODE>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
+        return gauss_slide_band<R, CLAMP, NCH, RAGGED, false, AMODE, LOCKSTEP>(L, wv, alpha_hi, alpha_tab, q3, preloaded);
     };
     // 3 channels while alpha is 255; where that stops at a row of another UNIFORM alpha, 3 channels with the value
     // tracked (constant and piecewise-constant alpha); 4 channels for what is left.  A pass that stops hands the band to
@@ -609,17 +619,26 @@ hipError_t launch_r(hipStream_t stream, const uint8_t* d_in, uint8_t* d_out, int
     const uint32_t alpha_hi = coef.h_alpha_tab[255];
     const uint32_t* alpha_tab = coef.d_alpha_tab;
     const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
-#define MI355_LAUNCH1(CL, RG, MD)                                                                               \
-    hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG, MD>), grid, block, 0, stream, d_in, d_out, w, h, nstrips, \
+    // lock-step rows (see the row loop) where a workgroup is kWavesPerBlock adjacent strips of one band — with 5 strips
+    // per row (width 1023) the coupled waves belong to different bands and the same barrier costs 4 %, on one-strip
+    // frames 7 % — and the launch is several times what the chip holds at once (1-4 4K frames, cache-resident: -1.2 %)
+    const bool lockstep = R <= 2 && !ragged && nstrips % kWavesPerBlock == 0 && plan.nwork_b == 0 && plan.nwork_a >= 8192u;
+#define MI355_LAUNCH1(CL, RG, MD, LS)                                                                               \
+    hipLaunchKernelGGL((gauss_slide_kernel<R, CL, RG, MD, LS>), grid, block, 0, stream, d_in, d_out, w, h, nstrips, \
                        lanes_out, plan, wts, alpha_hi, alpha_tab, d_flags)
-#define MI355_LAUNCH(CL, RG)        \
-    do {                            \
-        if constexpr (kSplit) {     \
-            MI355_LAUNCH1(CL, RG, 3); \
-            MI355_LAUNCH1(CL, RG, 4); \
-        } else {                    \
-            MI355_LAUNCH1(CL, RG, 0); \
-        }                           \
+#define MI355_LAUNCH(CL, RG)                  \
+    do {                                      \
+        if constexpr (kSplit) {               \
+            MI355_LAUNCH1(CL, RG, 3, false);  \
+            MI355_LAUNCH1(CL, RG, 4, false);  \
+        } else if constexpr (!RG) {           \
+            if (lockstep)                     \
+                MI355_LAUNCH1(CL, RG, 0, true);  \
+            else                              \
+                MI355_LAUNCH1(CL, RG, 0, false); \
+        } else {                              \
+            MI355_LAUNCH1(CL, RG, 0, false);  \
+        }                                     \
     } while (0)
     if (clamp && ragged)
         MI355_LAUNCH(true, true);

@@ -723,6 +723,49 @@ def test_big_batch_kernels(ctx, pkg, oracle):
     ctx.free(d_in)
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("k,sigma", [(3, 0.8), (5, 1.5)])
+def test_gauss_lockstep_rows_with_strips_that_leave_early(ctx, pkg, oracle, k, sigma):
+    """Big launches of frames whose strips come in fours (gauss_slide.hip: LOCKSTEP — a workgroup is four adjacent
+    strips of one band, one s_barrier per row): 200 frames of 960 x 264 = 4 strips x 11 (k = 5) or 22 (k = 3) bands, >=
+    8192 work items.  Strips that stop their 3-channel pass early (alpha noise in ONE strip's columns, a constant from
+    some row on, one stray pixel, noise everywhere) sit in one workgroup with strips that do not: nobody may wait for
+    ever, and the bytes are the tiled kernel's over the whole batch and within 1 LSB of the CPU path."""
+    w, h, n = 960, 264, 200
+    per = w * h * 4
+    assert (w // 4) % 60 == 0 and ((w // 4) // 60) % 4 == 0 and 4 * (-(-h // 24)) * n >= 8192
+    d_in = ctx.alloc(per * n)
+    ctx.synth_dev(d_in, w, h, n, first_frame=0, seed=0x5EED, mode=0)
+    frames = np.empty((n, h, w, 4), np.uint8)
+    ctx.d2h(frames, d_in)
+    rng = np.random.default_rng(k)
+    touched = [3, 5, 7, 9, 11, 64, 199]
+    frames[3, :, 240:480, 3] = rng.integers(0, 256, (h, 240), dtype=np.uint8)   # strip 1 alone leaves at its first row
+    frames[5, 100:, 480:720, 3] = 128                                           # strip 2: a constant from row 100 on
+    frames[7, :, :, 3] = rng.integers(0, 256, (h, w), dtype=np.uint8)           # every strip leaves
+    frames[9, 131, 500, 3] = 0                                                  # one pixel
+    frames[11, :, :, 3] = 77                                                    # the constant-alpha pass everywhere
+    frames[64, 24:48, :240, 3] = 200                                            # exactly one band of strip 0
+    frames[199, h - 1, w - 1, 3] = 1                                            # the very last pixel of the launch
+    ctx.h2d(d_in, frames)
+    outs = {}
+    for impl in (pkg.IMPL_TILE, pkg.IMPL_VALU):
+        ctx.set_gauss_mode(pkg.GAUSS_FAST)
+        ctx.set_impl(impl)
+        d_out = ctx.alloc(per * n)
+        ctx.filter_dev(pkg.FILTER_GAUSS, d_in, d_out, w, h, n, k, sigma)
+        got = np.empty((n, h, w, 4), np.uint8)
+        ctx.d2h(got, d_out)
+        ctx.free(d_out)
+        outs[impl] = got
+    ctx.set_impl(pkg.IMPL_AUTO)
+    ctx.free(d_in)
+    assert np.array_equal(outs[pkg.IMPL_VALU], outs[pkg.IMPL_TILE])
+    for f in touched + [0]:
+        ref = oracle.gauss_rgba(frames[f], k, sigma)
+        assert np.abs(outs[pkg.IMPL_VALU][f].astype(np.int16) - ref.astype(np.int16)).max() <= 1, f
+
+
 def test_gray_content_takes_the_table_path_and_stays_bit_exact(ctx, pkg, oracle):
     """On gray content (r = g = b: monochrome cameras, documents, the reference's Artemis photographs) every pixel sits on
     the luminance's ambiguous case S = 1000 v; gray pixels then read luma(v, v, v) from a 256-byte table instead of

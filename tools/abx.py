@@ -80,10 +80,17 @@ def main():
     import tempfile
     for name in hargs.libs.split(","):
         tune = {}
-        if name.startswith("T:"):   # T:BAND_ROWS=48:LANES_OUT=56 -> a private copy of the tuning build with MI355_TUNE_* set
-            tune = dict(kv.split("=") for kv in name[2:].split(":"))
-            path = os.path.join(tempfile.mkdtemp(prefix="abx_"), "libtune_%s.so" % name[2:].replace(":", "_").replace("=", ""))
-            shutil.copy(os.path.join(libdir, "libmi355_imgfilter_tune.so"), path)
+        if name.startswith("T:") or name.startswith("T@"):
+            # T:BAND_ROWS=48:LANES_OUT=56 -> a private copy of the tuning build with MI355_TUNE_* set;
+            # T@ab/lib_x.so:BAND_ROWS=48 -> the same for a tuning build made by VARIANT_TUNE=1 tools/build_variant.sh
+            src = os.path.join(libdir, "libmi355_imgfilter_tune.so")
+            spec = name[2:]
+            if name[1] == "@":
+                src, _, spec = spec.partition(":")
+                src = src if os.path.isabs(src) else os.path.join(ROOT, src)
+            tune = dict(kv.split("=") for kv in spec.split(":")) if spec else {}
+            path = os.path.join(tempfile.mkdtemp(prefix="abx_"), "libtune_%s.so" % name[2:].replace(":", "_").replace("=", "").replace("/", "_"))
+            shutil.copy(src, path)
         else:
             path = {"B": None, "T": os.path.join(libdir, "libmi355_imgfilter_tune.so")}.get(name, name)
         if path is not None and not os.path.isabs(path):
@@ -93,7 +100,7 @@ def main():
         lib = pkg.imgfilter.load_library(path) if path else pkg.load_library()
         label = name if path is None or name[0] == "T" else os.path.basename(path).replace("lib_", "").replace(".so", "")
         ctx = pkg.Context(0, stream=stream.cuda_stream, lib=lib)
-        if tune:
+        if name[0] == "T" and name[1:2] in (":", "@"):
             # the overrides are read once, at the first launch of each kernel family: make those launches now
             t_in = torch.zeros((1, 64, 256, 4), dtype=torch.uint8, device=dev)
             t_out = torch.zeros((1, 64, 256, 4), dtype=torch.uint8, device=dev)
