@@ -202,7 +202,11 @@ int mi355_host_free(mi355_ctx* ctx, void* h_ptr);
  * accesses — so an in-place or overlapping call is rejected with MI355_ERR_BAD_ARG, for every filter, instead of
  * returning corrupted pixels.  (The reference never aliases them either: two clCreateBuffer objects per call.)
  * These are what a caller that already owns device memory (torch, a capture pipeline) binds, and
- * what the roofline measurement times (no PCIe in the timed region). */
+ * what the roofline measurement times (no PCIe in the timed region).
+ * Stream capture: after the first call with a given (k, sigma) and frame size — which installs the weight table and
+ * sizes the scratch buffers, synchronising the stream — these calls allocate nothing and wait for nothing, so they may
+ * be issued while the context's stream is being captured into a hipGraph and replayed later
+ * (tests/test_gpu_configs.py: test_device_resident_calls_can_be_captured_into_a_hip_graph; tools/graph_probe.py). */
 int mi355_gray_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
 int mi355_gray1_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes);
 int mi355_gauss_rgba8_dev(mi355_ctx* ctx, const void* d_in, void* d_out, int w, int h, int nframes,
