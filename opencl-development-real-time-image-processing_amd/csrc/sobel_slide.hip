@@ -45,7 +45,14 @@ __device__ __forceinline__ float dpp_right(float v)  // lane l <- lane l+1
 // RAGGED = width % 4 != 0 or unaligned buffers: interior strips use unaligned 16-byte row accesses, the two
 // edge strips address their pixels one by one through reflect-101 (which also covers the partial last quad),
 // and the output row (1 byte per pixel, width bytes long) is written byte by byte in the edge strips.
-template <bool RAGGED>
+// LOCKSTEP (aligned instantiation, mid-size launches): one s_barrier per row keeps the four waves of a workgroup —
+// adjacent strips, or the end of one row-band and the start of the next — to the same row, so their 1-KiB loads and
+// 240-byte stores reach the memory system together.  Same box and buffers, 60-lane strips: 4K x 10 / 16 / 20 / 32 frames
+// +3 / +7.5 / +8.7 / +7.2 %, 1080p x 48-128 +4 to +7 %, 720p, 1440p, 1600 x 1200, 640 x 480 (3-11 strips per row: no multiple
+// of four needed here) +5 to +7 %; launches of 1-4 frames lose 5-7 % with it and ragged widths 0-5 %, so those keep
+// LOCKSTEP = false; from 2^28 pixels the aligned-strip kernel below takes over (profiles/r03_sobel_lockstep_ab.txt).
+// A wave that runs out of rows simply ends: s_barrier waits for the waves of the group that have not terminated.
+template <bool RAGGED, bool LOCKSTEP>
 __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
     const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int w, int h, int nstrips, int lanes_out,
     BandPlan plan)
@@ -127,6 +134,8 @@ __global__ __launch_bounds__(kWavesPerBlock * 64) void sobel_slide_kernel(
         for (int u = 0; u < K; u++) {
             const int i = base + u;
             u32x4 p = q[u];
+            if constexpr (LOCKSTEP)
+                __builtin_amdgcn_s_barrier();
             q[(u + PF) % K] = load_row(i + PF);
             if constexpr (!RAGGED) {
                 if (edge_strip) {
@@ -354,12 +363,19 @@ hipError_t launch_sobel_slide(hipStream_t stream, const uint8_t* d_in, uint8_t* 
         return hipErrorInvalidValue;
     const bool ragged = (w & 3) != 0 || (reinterpret_cast<uintptr_t>(d_in) & 15u) != 0 ||
                         (reinterpret_cast<uintptr_t>(d_out) & 3u) != 0;
+    // mid-size launches of aligned rows (8 x 10^7 pixels ~ ten 4K frames, up to where the strip kernel takes over): rows in
+    // lock-step, see the kernel
+    const bool lockstep = !ragged && !big && (size_t)w * h * nframes >= 80000000ull;
+    const dim3 grid(plan.nblocks_a + plan.nblocks_b), block(kWavesPerBlock * 64);
     if (ragged)
-        hipLaunchKernelGGL(sobel_slide_kernel<true>, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, w, h, sp.nstrips, sp.lanes_out, plan);
+        hipLaunchKernelGGL((sobel_slide_kernel<true, false>), grid, block, 0, stream, d_in, d_out, w, h, sp.nstrips,
+                           sp.lanes_out, plan);
+    else if (lockstep)
+        hipLaunchKernelGGL((sobel_slide_kernel<false, true>), grid, block, 0, stream, d_in, d_out, w, h, sp.nstrips,
+                           sp.lanes_out, plan);
     else
-        hipLaunchKernelGGL(sobel_slide_kernel<false>, dim3(plan.nblocks_a + plan.nblocks_b), dim3(kWavesPerBlock * 64), 0,
-                           stream, d_in, d_out, w, h, sp.nstrips, sp.lanes_out, plan);
+        hipLaunchKernelGGL((sobel_slide_kernel<false, false>), grid, block, 0, stream, d_in, d_out, w, h, sp.nstrips,
+                           sp.lanes_out, plan);
     return hipGetLastError();
 }
 

@@ -766,6 +766,40 @@ def test_gauss_lockstep_rows_with_strips_that_leave_early(ctx, pkg, oracle, k, s
         assert np.abs(outs[pkg.IMPL_VALU][f].astype(np.int16) - ref.astype(np.int16)).max() <= 1, f
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 40), (1280, 725, 87)])
+def test_sobel_lockstep_rows_on_mid_size_launches(ctx, pkg, oracle, w, h, n):
+    """Launches of 8 x 10^7 pixels and more (below the 2^28 where the aligned-strip kernel takes over) run the halo-lane
+    Sobel kernel with one s_barrier per row (sobel_slide.hip: LOCKSTEP).  1920 x 1080: 8 strips per row, a workgroup is
+    four adjacent strips; 1280 x 725: 6 strips, 46 bands of which the last has 5 rows — workgroups straddle rows and bands
+    of different length, waves run out of rows at different times.  The whole launch must equal the same frames run four
+    at a time (no barrier there: checksums add up over the word index), first and last frame must equal the oracle."""
+    per = w * h
+    assert 80_000_000 <= per * n < (1 << 28)
+    d_in = ctx.alloc(per * n * 4)
+    ctx.synth_dev(d_in, w, h, n, first_frame=0, seed=0x5EED, mode=0)
+    d_out = ctx.alloc(per * n)
+    ctx.filter_dev(pkg.FILTER_SOBEL, d_in, d_out, w, h, n)
+    whole = ctx.checksum_dev(d_out, per * n)
+    got_first = np.empty((h, w), np.uint8)
+    got_last = np.empty((h, w), np.uint8)
+    ctx.d2h(got_first, d_out)
+    ctx.d2h(got_last, d_out + (n - 1) * per)
+    step = 4 if (per * 4) % 4 == 0 else 1
+    d_part = ctx.alloc(per * step)
+    parts = 0
+    for f in range(0, n, step):
+        m = min(step, n - f)
+        ctx.filter_dev(pkg.FILTER_SOBEL, d_in + f * per * 4, d_part, w, h, m)
+        parts += ctx.checksum_dev(d_part, per * m, index_base=f * per // 4)
+    assert parts % (1 << 64) == whole
+    for f, got in ((0, got_first), (n - 1, got_last)):
+        frame = oracle.synth_rgba(w, h, 1, first_frame=f, seed=0x5EED, mode=0)[0]
+        assert np.array_equal(got, oracle.sobel_rgba(frame).reshape(h, w))
+    for d in (d_part, d_out, d_in):
+        ctx.free(d)
+
+
 def test_gray_content_takes_the_table_path_and_stays_bit_exact(ctx, pkg, oracle):
     """On gray content (r = g = b: monochrome cameras, documents, the reference's Artemis photographs) every pixel sits on
     the luminance's ambiguous case S = 1000 v; gray pixels then read luma(v, v, v) from a 256-byte table instead of
