@@ -15,6 +15,10 @@ row --filter gauss --k 11 --sigma 3.0 --frames 64
 row --filter gauss --k 13 --sigma 3.3 --frames 64
 row --filter gauss --k 17 --sigma 6 --frames 64
 row --filter sobel
+# mid-size Sobel launches (8 x 10^7 .. 2^28 pixels: the halo-lane kernel with rows in lock-step), steps scaled to >= 100 ms
+row --filter sobel --frames 16 --steps 800 --warmup 80
+row --filter sobel --frames 32 --steps 400 --warmup 40
+row --filter sobel --width 1920 --height 1080 --frames 64 --steps 800 --warmup 80
 row --filter pipeline --k 3
 row --filter pipeline
 row --filter pipeline --k 7
